@@ -1,0 +1,160 @@
+/*
+ * ldit.h - C ABI of libldit_hip.so: the MI355X (gfx950) ViT / DiT encoder forward behind LayoutDiT's DiTBackbone.
+ *
+ * The reference has no FFI: its seam is the Python attribute `DiTBackbone.dit`, a HuggingFace `BeitModel`
+ * (ref src/layoutdit/modeling/dit_backbone.py:26-31) whose only use is
+ *     hs = self.dit(x).hidden_states            (ref src/layoutdit/modeling/dit_backbone.py:47)
+ * Every entry point below replaces a piece of what that one line executes; the citations name the reference (ref:)
+ * or the third-party code it delegates to (TF: = transformers models/beit/modeling_beit.py, pinned 4.49.0 at
+ * ref uv.lock:1771-1772; line numbers from the installed 5.15.0 copy).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `ldit_stream` is a hipStream_t passed as void* (NULL = default stream)
+ *   - every pointer is a DEVICE pointer owned by the caller, 16-byte aligned, fp32 unless stated
+ *   - the library allocates nothing, keeps no mutable global state, and only ENQUEUES work on `stream`
+ *     (asynchronous to the host; the caller synchronises) - safe to capture in a hipGraph
+ *   - returns LDIT_OK (0) or a negative LDIT_E* code; ldit_last_error() returns a thread-local message
+ *   - there is NO CPU fallback in this library: without a HIP device every compute entry point fails with LDIT_EHIP
+ */
+#ifndef LDIT_H
+#define LDIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDIT_ABI_VERSION 1
+#define LDIT_MAX_TAPS 8
+
+enum ldit_status {
+    LDIT_OK = 0,
+    LDIT_EINVAL = -1,       /* bad argument (null pointer, misaligned, inconsistent geometry) */
+    LDIT_EWORKSPACE = -2,   /* workspace / packed buffer too small */
+    LDIT_EHIP = -3,         /* HIP runtime error (message in ldit_last_error) */
+    LDIT_EUNSUPPORTED = -4  /* geometry outside what the kernels handle (see each function) */
+};
+
+enum ldit_dtype { LDIT_F32 = 0 };
+
+/* epilogues of ldit_linear_f32 (what is fused behind the matmul) */
+enum ldit_epilogue {
+    LDIT_EPI_BIAS = 0,       /* Y = X W^T + b                         nn.Linear; TF:305-307 (q,k,v), TF:349 */
+    LDIT_EPI_BIAS_GELU = 1,  /* Y = gelu_erf(X W^T + b)               TF:353-354, TF:activations.py:70-89 */
+    LDIT_EPI_SCALE_RESID = 2 /* Y = R + lam (.) (X W^T + b)           TF:432-434 and TF:440-442 (LayerScale + residual) */
+};
+
+typedef void *ldit_stream;
+
+/* Encoder geometry.  Mirrors the BeitConfig fields the path reads (TF:configuration_beit.py:72-102). */
+typedef struct ldit_cfg {
+    int32_t hidden;   /* C   hidden_size */
+    int32_t layers;   /* L   num_hidden_layers */
+    int32_t heads;    /* H   num_attention_heads ; head_dim = C / H */
+    int32_t mlp;      /* F   intermediate_size */
+    int32_t patch;    /* p   patch_size (square) */
+    int32_t in_ch;    /* num_channels (3) */
+    int32_t img_h;    /* input height, multiple of patch */
+    int32_t img_w;    /* input width,  multiple of patch */
+    int32_t n_taps;   /* how many hidden states the caller wants (<= LDIT_MAX_TAPS) */
+    int32_t taps[LDIT_MAX_TAPS]; /* hidden-state indices, 0 = embedding output, l = after layer l
+                                    (ref dit_backbone.py:33-34: d/3, d/2, 2d/3, d) */
+    float ln_eps;     /* layer_norm_eps, 1e-12 for BEiT */
+    int32_t dtype;    /* enum ldit_dtype */
+    int32_t flags;    /* reserved, 0 */
+} ldit_cfg;
+
+/* Per-layer parameters, each exactly the tensor nn.Module.state_dict() holds (row-major [out, in] for Linear). */
+typedef struct ldit_layer_weights {
+    const void *ln1_w, *ln1_b;        /* layernorm_before        [C]       TF:390,426 */
+    const void *wq, *bq;              /* attention q_proj        [C,C],[C] TF:305 */
+    const void *wk;                   /* attention k_proj        [C,C]     TF:306 (NO bias) */
+    const void *wv, *bv;              /* attention v_proj        [C,C],[C] TF:307 */
+    const void *wo, *bo;              /* attention o_proj        [C,C],[C] TF:308 */
+    const void *lam1;                 /* lambda_1                [C]       TF:397-403 */
+    const void *ln2_w, *ln2_b;        /* layernorm_after         [C]       TF:391,438 */
+    const void *w1, *b1;              /* mlp.fc1                 [F,C],[F] TF:349 */
+    const void *w2, *b2;              /* mlp.fc2                 [C,F],[C] TF:350 */
+    const void *lam2;                 /* lambda_2                [C] */
+} ldit_layer_weights;
+
+typedef struct ldit_weights {
+    const void *patch_w;              /* embeddings.patch_embeddings.projection.weight [C,in_ch,p,p]  TF:81 */
+    const void *patch_b;              /* ....projection.bias [C] */
+    const void *cls;                  /* embeddings.cls_token [C]                                    TF:168 */
+    const void *pos;                  /* position table for THIS input grid, [1 + (img_h/p)*(img_w/p), C]
+                                         (= embeddings.position_embeddings when the grid is the table's own;
+                                         otherwise the caller resamples it bicubically first, TF:113-151) */
+    const ldit_layer_weights *layer;  /* HOST array of `layers` entries */
+} ldit_weights;
+
+/* ---- library ------------------------------------------------------------------------------------------------ */
+int ldit_abi_version(void);
+const char *ldit_last_error(void);
+
+/* ---- whole path: replaces `self.dit(x).hidden_states` (ref dit_backbone.py:47 ; TF:515-560) ------------------- */
+
+/* Bytes of the packed parameter block for this geometry (one allocation the forward streams from). */
+size_t ldit_packed_bytes(const ldit_cfg *cfg);
+
+/* Gather the caller's parameter tensors into `packed` (device), fusing q/k/v into one [3C,C] matrix with bias
+ * [bq ; 0 ; bv] (the key projection has no bias, TF:306).  Call again whenever parameters change. */
+int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, size_t packed_bytes, ldit_stream stream);
+
+/* Scratch bytes ldit_vit_forward needs for a batch of `batch` images. */
+size_t ldit_workspace_bytes(const ldit_cfg *cfg, int32_t batch);
+
+/* x: [batch, in_ch, img_h, img_w] NCHW contiguous.  tap_out[i]: [batch, 1+P, C] row-major receives hidden state
+ * cfg->taps[i] (the raw residual stream: no final LayerNorm, TF:504-506,557).  The pooler (TF:558,563-572) is not
+ * computed: LayoutDiT never reads pooler_output. */
+int ldit_vit_forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batch, void *const *tap_out,
+                     void *workspace, size_t workspace_bytes, ldit_stream stream);
+
+/* Same, but brackets every kernel launch with HIP events on `stream`, synchronises, and ADDS the elapsed
+ * milliseconds / launch counts per kernel family into ms[LDIT_K_COUNT] / launches[LDIT_K_COUNT].
+ * Measurement aid for bench.py's roofline block; not for production use (it blocks the host). */
+enum ldit_kernel_family {
+    LDIT_K_GEMM = 0,      /* all MFMA GEMMs: patch-embed, qkv, o_proj, fc1, fc2 */
+    LDIT_K_ATTENTION = 1,
+    LDIT_K_LAYERNORM = 2,
+    LDIT_K_OTHER = 3,
+    LDIT_K_COUNT = 4
+};
+int ldit_vit_forward_timed(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batch, void *const *tap_out,
+                           void *workspace, size_t workspace_bytes, ldit_stream stream, double *ms, int64_t *launches);
+
+/* ---- the kernels, one entry point each (unit parity tests; also usable on their own) -------------------------- */
+
+/* Y[M,N] = epilogue(X[M,K] . W[N,K]^T).  fp32 MFMA.  K % 32 == 0, lda/ldy % 4 == 0.
+ * bias[N] may be NULL (= 0).  lam[N], R[M,N] (row stride ldy) only for LDIT_EPI_SCALE_RESID; R may alias Y.
+ * Y2 (optional, same shape/stride as Y) receives a second copy of the result (hidden-state tap). */
+int ldit_linear_f32(const void *X, int64_t lda, const void *W, const void *bias, void *Y, int64_t ldy, int64_t M,
+                    int64_t N, int64_t K, int32_t epilogue, const void *lam, const void *R, void *Y2,
+                    ldit_stream stream);
+
+/* Row LayerNorm over the last axis, biased variance about the mean, y = (x-mu) rsqrt(var+eps) g + b.
+ * C % 4 == 0, C <= 4096.  (nn.LayerNorm; TF:390-391,426,438) */
+int ldit_layernorm_f32(const void *X, const void *gamma, const void *beta, void *Y, int64_t rows, int64_t C, float eps,
+                       ldit_stream stream);
+
+/* softmax(Q K^T * scale) V per head, no mask.  Q,K,V,O: [B, N, H*D] token-major with row strides ldq..ldo (floats);
+ * head h occupies columns [h*D, (h+1)*D).  D == 64.  (TF:268-293, TF:323-338) */
+int ldit_attention_f32(const void *Q, const void *K, const void *V, void *O, int64_t B, int64_t N, int64_t H,
+                       int64_t D, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, ldit_stream stream);
+
+/* Patch embedding + [cls ; patches] + position table (TF:81-90, TF:153-176).
+ * x [B,in_ch,img_h,img_w] NCHW -> out [B, 1+P, C].  (in_ch*p*p) % 32 == 0, p % 4 == 0, img_w % 4 == 0. */
+int ldit_embed_f32(const void *x, const void *patch_w, const void *patch_b, const void *cls, const void *pos, void *out,
+                   int64_t B, int64_t in_ch, int64_t img_h, int64_t img_w, int64_t p, int64_t C, ldit_stream stream);
+
+/* DiTBackbone tap post-processing (ref dit_backbone.py:50-61): drop CLS, view tokens as a [C,Gh,Gw] map, bilinear
+ * rescale by `scale` in {4, 2, 1, 0.5} (align_corners=False).  tap [B,1+Gh*Gw,C] -> out [B,C,Gh*scale,Gw*scale] NCHW. */
+int ldit_tap_to_map_f32(const void *tap, void *out, int64_t B, int64_t Gh, int64_t Gw, int64_t C, float scale,
+                        ldit_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDIT_H */

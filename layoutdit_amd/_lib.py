@@ -1,0 +1,89 @@
+"""ctypes binding of ``libldit_hip.so`` (C ABI: ``include/ldit.h``).
+
+The library is the product; this module only loads it and describes its signatures.  There is deliberately no
+fallback: if the shared object is missing or a symbol is absent, import of the compute path fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libldit_hip.so")
+
+LDIT_ABI_VERSION = 1
+LDIT_MAX_TAPS = 8
+LDIT_OK, LDIT_EINVAL, LDIT_EWORKSPACE, LDIT_EHIP, LDIT_EUNSUPPORTED = 0, -1, -2, -3, -4
+EPI_BIAS, EPI_BIAS_GELU, EPI_SCALE_RESID = 0, 1, 2
+K_GEMM, K_ATTENTION, K_LAYERNORM, K_OTHER, K_COUNT = 0, 1, 2, 3, 4
+KERNEL_FAMILIES = ("gemm", "attention", "layernorm", "other")
+
+
+class LditCfg(C.Structure):
+    _fields_ = [("hidden", C.c_int32), ("layers", C.c_int32), ("heads", C.c_int32), ("mlp", C.c_int32),
+                ("patch", C.c_int32), ("in_ch", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32),
+                ("n_taps", C.c_int32), ("taps", C.c_int32 * LDIT_MAX_TAPS), ("ln_eps", C.c_float),
+                ("dtype", C.c_int32), ("flags", C.c_int32)]
+
+
+LAYER_FIELDS = ("ln1_w", "ln1_b", "wq", "bq", "wk", "wv", "bv", "wo", "bo", "lam1",
+                "ln2_w", "ln2_b", "w1", "b1", "w2", "b2", "lam2")
+
+
+class LditLayerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in LAYER_FIELDS]
+
+
+class LditWeights(C.Structure):
+    _fields_ = [("patch_w", C.c_void_p), ("patch_b", C.c_void_p), ("cls", C.c_void_p), ("pos", C.c_void_p),
+                ("layer", C.POINTER(LditLayerWeights))]
+
+
+# name -> (restype, argtypes); every symbol include/ldit.h declares
+_vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
+SIGNATURES = {
+    "ldit_abi_version": (C.c_int, []),
+    "ldit_last_error": (C.c_char_p, []),
+    "ldit_packed_bytes": (_sz, [C.POINTER(LditCfg)]),
+    "ldit_pack_weights": (C.c_int, [C.POINTER(LditCfg), C.POINTER(LditWeights), _vp, _sz, _vp]),
+    "ldit_workspace_bytes": (_sz, [C.POINTER(LditCfg), _i32]),
+    "ldit_vit_forward": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _i32, C.POINTER(_vp), _vp, _sz, _vp]),
+    "ldit_vit_forward_timed": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _i32, C.POINTER(_vp), _vp, _sz, _vp,
+                                         C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ldit_linear_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "ldit_layernorm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp]),
+    "ldit_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp]),
+    "ldit_embed_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "ldit_tap_to_map_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
+}
+
+_lib = None
+
+
+class LditError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libldit_hip: error {code}: {message}")
+        self.code = code
+
+
+def load() -> C.CDLL:
+    """Load the library (once).  Raises if it is missing - there is no other implementation to fall back to."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found: build it with `make -C layoutdit_amd/csrc` "
+                              f"(or __graft_entry__.build()); layoutdit_amd has no CPU / eager fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        got = lib.ldit_abi_version()
+        if got != LDIT_ABI_VERSION:
+            raise ImportError(f"libldit_hip ABI {got} != expected {LDIT_ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != LDIT_OK:
+        raise LditError(rc, load().ldit_last_error().decode(errors="replace"))

@@ -61,7 +61,7 @@ class DiTConfig:
 
 # Named geometries used by BASELINE.json's configs.
 def vit_micro() -> DiTConfig:   # golden G0: bit-for-bit debuggable
-    return DiTConfig(hidden_size=64, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256,
+    return DiTConfig(hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=512,
                      image_size=64)
 
 

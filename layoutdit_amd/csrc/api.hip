@@ -1,0 +1,394 @@
+// C-ABI entry points of libldit_hip.so (declared in include/ldit.h).  Host-side sequencing only: every byte of
+// arithmetic happens in the HIP kernels of this directory; there is no CPU fallback.
+#include <cstring>
+#include <vector>
+
+#include "ldit_common.h"
+
+namespace ldit {
+
+char *err_buf()
+{
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+namespace {
+
+inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Geo {
+    int C, L, H, F, D, p, in_ch, gh, gw, P, T, Kp;   // T tokens per image, Kp = in_ch*p*p
+};
+
+int geometry(const ldit_cfg *cfg, Geo &g)
+{
+    if (!cfg) return fail(LDIT_EINVAL, "cfg is null");
+    if (cfg->dtype != LDIT_F32) return fail(LDIT_EUNSUPPORTED, "dtype %d: only fp32 is implemented", cfg->dtype);
+    g.C = cfg->hidden; g.L = cfg->layers; g.H = cfg->heads; g.F = cfg->mlp; g.p = cfg->patch; g.in_ch = cfg->in_ch;
+    if (g.C <= 0 || g.L < 0 || g.H <= 0 || g.F <= 0 || g.p <= 0 || g.in_ch <= 0) return fail(LDIT_EINVAL, "cfg: non-positive dimension");
+    if (g.C % g.H) return fail(LDIT_EINVAL, "cfg: hidden %d not divisible by heads %d", g.C, g.H);
+    g.D = g.C / g.H;
+    if (g.D != 64) return fail(LDIT_EUNSUPPORTED, "cfg: head_dim %d, only 64 is implemented", g.D);
+    if (g.C % 32 || g.F % 32) return fail(LDIT_EUNSUPPORTED, "cfg: hidden and mlp must be multiples of 32");
+    if (cfg->img_h <= 0 || cfg->img_w <= 0 || cfg->img_h % g.p || cfg->img_w % g.p)
+        return fail(LDIT_EINVAL, "cfg: image %dx%d is not a multiple of patch %d", cfg->img_h, cfg->img_w, g.p);
+    g.gh = cfg->img_h / g.p; g.gw = cfg->img_w / g.p; g.P = g.gh * g.gw; g.T = g.P + 1;
+    g.Kp = g.in_ch * g.p * g.p;
+    if (g.Kp % 32 || g.p % 4) return fail(LDIT_EUNSUPPORTED, "cfg: in_ch*patch^2 must be a multiple of 32 and patch of 4");
+    if (cfg->n_taps < 0 || cfg->n_taps > LDIT_MAX_TAPS) return fail(LDIT_EINVAL, "cfg: n_taps %d out of range", cfg->n_taps);
+    for (int i = 0; i < cfg->n_taps; ++i)
+        if (cfg->taps[i] < 0 || cfg->taps[i] > g.L) return fail(LDIT_EINVAL, "cfg: tap %d outside [0, %d]", cfg->taps[i], g.L);
+    return LDIT_OK;
+}
+
+// Offsets (in floats) into the packed parameter block; every offset is a multiple of 4 floats.
+struct PackedLayer { size_t ln1_w, ln1_b, wqkv, bqkv, wo, bo, lam1, ln2_w, ln2_b, w1, b1, w2, b2, lam2; };
+struct PackedMap {
+    size_t patch_w, patch_b, cls, pos, total;
+    std::vector<PackedLayer> layer;
+};
+
+PackedMap packed_map(const Geo &g)
+{
+    PackedMap m;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += up(n, 4); return at; };
+    m.patch_w = take((size_t)g.C * g.Kp);
+    m.patch_b = take(g.C);
+    m.cls = take(g.C);
+    m.pos = take((size_t)g.T * g.C);
+    m.layer.resize(g.L);
+    for (int l = 0; l < g.L; ++l) {
+        PackedLayer &pl = m.layer[l];
+        pl.ln1_w = take(g.C); pl.ln1_b = take(g.C);
+        pl.wqkv = take((size_t)3 * g.C * g.C); pl.bqkv = take((size_t)3 * g.C);
+        pl.wo = take((size_t)g.C * g.C); pl.bo = take(g.C); pl.lam1 = take(g.C);
+        pl.ln2_w = take(g.C); pl.ln2_b = take(g.C);
+        pl.w1 = take((size_t)g.F * g.C); pl.b1 = take(g.F);
+        pl.w2 = take((size_t)g.C * g.F); pl.b2 = take(g.C); pl.lam2 = take(g.C);
+    }
+    m.total = o;
+    return m;
+}
+
+struct Workspace { size_t h, y, big, total; };   // byte offsets
+
+Workspace workspace_map(const Geo &g, int batch)
+{
+    const size_t M = (size_t)batch * g.T;
+    const size_t wide = (size_t)(3 * g.C > g.F ? 3 * g.C : g.F);
+    Workspace w;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += up(bytes, 256); return at; };
+    w.h = take(M * g.C * 4);       // residual stream
+    w.y = take(M * g.C * 4);       // LayerNorm output, then attention output
+    w.big = take(M * wide * 4);    // fused q|k|v, later the MLP hidden (never live together)
+    w.total = o;
+    return w;
+}
+
+// Optional per-launch HIP-event bracketing (ldit_vit_forward_timed).
+struct Probe {
+    bool on = false;
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> fam;
+    int begin(int family)
+    {
+        if (!on) return LDIT_OK;
+        hipEvent_t a, b;
+        LDIT_HIP_CHECK(hipEventCreate(&a));
+        LDIT_HIP_CHECK(hipEventCreate(&b));
+        ev.push_back(a); ev.push_back(b); fam.push_back(family);
+        LDIT_HIP_CHECK(hipEventRecord(a, stream));
+        return LDIT_OK;
+    }
+    int end()
+    {
+        if (!on) return LDIT_OK;
+        LDIT_HIP_CHECK(hipEventRecord(ev.back(), stream));
+        return LDIT_OK;
+    }
+    int collect(double *ms, int64_t *launches)
+    {
+        if (!on) return LDIT_OK;
+        LDIT_HIP_CHECK(hipStreamSynchronize(stream));
+        for (size_t i = 0; i < fam.size(); ++i) {
+            float t = 0.f;
+            LDIT_HIP_CHECK(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+            ms[fam[i]] += (double)t;
+            launches[fam[i]] += 1;
+        }
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear(); fam.clear();
+        return LDIT_OK;
+    }
+};
+
+#define LDIT_TRY(expr)                 \
+    do {                               \
+        int rc__ = (expr);             \
+        if (rc__ != LDIT_OK) return rc__; \
+    } while (0)
+
+#define LDIT_RUN(probe, family, expr)  \
+    do {                               \
+        LDIT_TRY((probe).begin(family)); \
+        LDIT_TRY(expr);                \
+        LDIT_TRY((probe).end());       \
+    } while (0)
+
+int embed(const Geo &g, const float *x, const float *pw, const float *pb, const float *cls, const float *pos, float *out,
+          int batch, int img_h, int img_w, hipStream_t stream, Probe &probe)
+{
+    GemmArgs a{};
+    a.A = x; a.W = pw; a.Y = out; a.Y2 = nullptr; a.bias = pb; a.pos = pos;
+    a.M = batch * g.P; a.N = g.C; a.K = g.Kp;
+    a.lda = g.in_ch * img_h * img_w;   // per-image stride in patch mode
+    a.ldy = g.C;
+    a.img_h = img_h; a.img_w = img_w; a.gw = g.gw; a.patches = g.P; a.patch = g.p; a.tokens = g.T;
+    LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm(a, EPI_EMBED, A_PATCH, stream));
+    LDIT_RUN(probe, LDIT_K_OTHER, launch_cls_rows(cls, pos, out, batch, g.T, g.C, stream));
+    return LDIT_OK;
+}
+
+int linear(const float *X, int lda, const float *W, const float *bias, float *Y, int ldy, int M, int N, int K, int epi,
+           const float *lam, const float *R, float *Y2, hipStream_t stream, Probe &probe)
+{
+    GemmArgs a{};
+    a.A = X; a.W = W; a.Y = Y; a.Y2 = Y2; a.bias = bias; a.lam = lam; a.R = R;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldy = ldy;
+    LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm(a, epi, A_ROWMAJOR, stream));
+    return LDIT_OK;
+}
+
+int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batch, void *const *tap_out, void *workspace,
+            size_t ws_bytes, hipStream_t stream, Probe &probe)
+{
+    Geo g;
+    LDIT_TRY(geometry(cfg, g));
+    if (batch <= 0) return fail(LDIT_EINVAL, "batch %d must be positive", batch);
+    if (!packed || !x || !workspace) return fail(LDIT_EINVAL, "null packed / x / workspace pointer");
+    if (!aligned16(packed) || !aligned16(x) || !aligned16(workspace)) return fail(LDIT_EINVAL, "pointers must be 16-byte aligned");
+    if (cfg->n_taps && !tap_out) return fail(LDIT_EINVAL, "tap_out is null");
+    for (int i = 0; i < cfg->n_taps; ++i)
+        if (!tap_out[i] || !aligned16(tap_out[i])) return fail(LDIT_EINVAL, "tap_out[%d] is null or misaligned", i);
+    if ((int64_t)batch * g.T * (int64_t)(g.F > 3 * g.C ? g.F : 3 * g.C) >= (1ll << 31))
+        return fail(LDIT_EUNSUPPORTED, "batch %d: activation index space exceeds 2^31 elements, split the batch", batch);
+    const Workspace wm = workspace_map(g, batch);
+    if (ws_bytes < wm.total) return fail(LDIT_EWORKSPACE, "workspace %zu bytes < required %zu", ws_bytes, wm.total);
+    const PackedMap pm = packed_map(g);
+    const float *P = static_cast<const float *>(packed);
+    char *ws = static_cast<char *>(workspace);
+    float *h = reinterpret_cast<float *>(ws + wm.h);
+    float *y = reinterpret_cast<float *>(ws + wm.y);
+    float *big = reinterpret_cast<float *>(ws + wm.big);
+    const int M = batch * g.T, C = g.C, F = g.F;
+    const size_t act_bytes = (size_t)M * C * 4;
+
+    auto tap_for = [&](int hidden_idx) -> float * {
+        for (int i = 0; i < cfg->n_taps; ++i)
+            if (cfg->taps[i] == hidden_idx) return static_cast<float *>(tap_out[i]);
+        return nullptr;
+    };
+    auto extra_taps = [&](int hidden_idx, const float *src, float *first) -> int {
+        // the same hidden state requested more than once: copy to the remaining destinations
+        for (int i = 0; i < cfg->n_taps; ++i)
+            if (cfg->taps[i] == hidden_idx && tap_out[i] != first)
+                LDIT_HIP_CHECK(hipMemcpyAsync(tap_out[i], src, act_bytes, hipMemcpyDeviceToDevice, stream));
+        return LDIT_OK;
+    };
+
+    // embeddings (TF:153-176)
+    LDIT_TRY(embed(g, static_cast<const float *>(x), P + pm.patch_w, P + pm.patch_b, P + pm.cls, P + pm.pos, h, batch,
+                   cfg->img_h, cfg->img_w, stream, probe));
+    if (float *t0 = tap_for(0)) {
+        LDIT_HIP_CHECK(hipMemcpyAsync(t0, h, act_bytes, hipMemcpyDeviceToDevice, stream));
+        LDIT_TRY(extra_taps(0, h, t0));
+    }
+
+    const float scale = 1.0f / sqrtf((float)g.D);
+    for (int l = 0; l < g.L; ++l) {
+        const PackedLayer &pl = pm.layer[l];
+        // y = LN1(h)                                                               TF:426
+        LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm(h, P + pl.ln1_w, P + pl.ln1_b, y, M, C, cfg->ln_eps, stream));
+        // big[:, 0:3C] = y . [Wq;Wk;Wv]^T + [bq;0;bv]                               TF:319-321
+        LDIT_TRY(linear(y, C, P + pl.wqkv, P + pl.bqkv, big, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, stream, probe));
+        // y = softmax(q k^T / sqrt(D)) v, heads merged token-major                 TF:323-338
+        LDIT_RUN(probe, LDIT_K_ATTENTION,
+                 launch_attention(big, big + C, big + 2 * C, y, batch, g.T, g.H, g.D, 3 * C, 3 * C, 3 * C, C, scale, stream));
+        // h += lam1 (.) (y . Wo^T + bo)                                             TF:339, 432-434
+        LDIT_TRY(linear(y, C, P + pl.wo, P + pl.bo, h, C, M, C, C, EPI_SCALE_RESID, P + pl.lam1, h, nullptr, stream, probe));
+        // y = LN2(h)                                                               TF:438
+        LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm(h, P + pl.ln2_w, P + pl.ln2_b, y, M, C, cfg->ln_eps, stream));
+        // big[:, 0:F] = gelu(y . W1^T + b1)                                         TF:353-354
+        LDIT_TRY(linear(y, C, P + pl.w1, P + pl.b1, big, F, M, F, C, EPI_BIAS_GELU, nullptr, nullptr, nullptr, stream, probe));
+        // h += lam2 (.) (big . W2^T + b2)  (+ tap copy of the new hidden state)      TF:355, 440-442
+        float *tap = tap_for(l + 1);
+        LDIT_TRY(linear(big, F, P + pl.w2, P + pl.b2, h, C, M, C, F, EPI_SCALE_RESID, P + pl.lam2, h, tap, stream, probe));
+        if (tap) LDIT_TRY(extra_taps(l + 1, h, tap));
+    }
+    return LDIT_OK;
+}
+
+}  // namespace
+}  // namespace ldit
+
+using namespace ldit;
+
+extern "C" {
+
+int ldit_abi_version(void) { return LDIT_ABI_VERSION; }
+
+const char *ldit_last_error(void) { return err_buf(); }
+
+size_t ldit_packed_bytes(const ldit_cfg *cfg)
+{
+    Geo g;
+    if (geometry(cfg, g) != LDIT_OK) return 0;
+    return packed_map(g).total * sizeof(float);
+}
+
+int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, size_t packed_bytes, ldit_stream stream_)
+{
+    Geo g;
+    LDIT_TRY(geometry(cfg, g));
+    if (!w || !packed) return fail(LDIT_EINVAL, "null weights / packed pointer");
+    if (!aligned16(packed)) return fail(LDIT_EINVAL, "packed must be 16-byte aligned");
+    if (g.L && !w->layer) return fail(LDIT_EINVAL, "weights->layer is null");
+    const PackedMap pm = packed_map(g);
+    if (packed_bytes < pm.total * sizeof(float)) return fail(LDIT_EWORKSPACE, "packed buffer %zu bytes < required %zu", packed_bytes, pm.total * sizeof(float));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    float *P = static_cast<float *>(packed);
+    auto put = [&](size_t off, const void *src, size_t n, const char *what) -> int {
+        if (!src) return fail(LDIT_EINVAL, "weights: %s is null", what);
+        LDIT_HIP_CHECK(hipMemcpyAsync(P + off, src, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        return LDIT_OK;
+    };
+    const size_t C = g.C, F = g.F;
+    LDIT_TRY(put(pm.patch_w, w->patch_w, C * g.Kp, "patch_w"));
+    LDIT_TRY(put(pm.patch_b, w->patch_b, C, "patch_b"));
+    LDIT_TRY(put(pm.cls, w->cls, C, "cls"));
+    LDIT_TRY(put(pm.pos, w->pos, (size_t)g.T * C, "pos"));
+    for (int l = 0; l < g.L; ++l) {
+        const ldit_layer_weights &s = w->layer[l];
+        const PackedLayer &pl = pm.layer[l];
+        LDIT_TRY(put(pl.ln1_w, s.ln1_w, C, "ln1_w"));
+        LDIT_TRY(put(pl.ln1_b, s.ln1_b, C, "ln1_b"));
+        LDIT_TRY(put(pl.wqkv, s.wq, C * C, "wq"));
+        LDIT_TRY(put(pl.wqkv + C * C, s.wk, C * C, "wk"));
+        LDIT_TRY(put(pl.wqkv + 2 * C * C, s.wv, C * C, "wv"));
+        if (!s.bq || !s.bv) return fail(LDIT_EINVAL, "weights: bq / bv is null");
+        LDIT_TRY(launch_pack_qkv_bias(static_cast<const float *>(s.bq), static_cast<const float *>(s.bv), P + pl.bqkv, g.C, stream));
+        LDIT_TRY(put(pl.wo, s.wo, C * C, "wo"));
+        LDIT_TRY(put(pl.bo, s.bo, C, "bo"));
+        LDIT_TRY(put(pl.lam1, s.lam1, C, "lam1"));
+        LDIT_TRY(put(pl.ln2_w, s.ln2_w, C, "ln2_w"));
+        LDIT_TRY(put(pl.ln2_b, s.ln2_b, C, "ln2_b"));
+        LDIT_TRY(put(pl.w1, s.w1, F * C, "w1"));
+        LDIT_TRY(put(pl.b1, s.b1, F, "b1"));
+        LDIT_TRY(put(pl.w2, s.w2, C * F, "w2"));
+        LDIT_TRY(put(pl.b2, s.b2, C, "b2"));
+        LDIT_TRY(put(pl.lam2, s.lam2, C, "lam2"));
+    }
+    return LDIT_OK;
+}
+
+size_t ldit_workspace_bytes(const ldit_cfg *cfg, int32_t batch)
+{
+    Geo g;
+    if (batch <= 0 || geometry(cfg, g) != LDIT_OK) return 0;
+    return workspace_map(g, batch).total;
+}
+
+int ldit_vit_forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batch, void *const *tap_out,
+                     void *workspace, size_t workspace_bytes, ldit_stream stream)
+{
+    Probe probe;
+    return forward(cfg, packed, x, batch, tap_out, workspace, workspace_bytes, static_cast<hipStream_t>(stream), probe);
+}
+
+int ldit_vit_forward_timed(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batch, void *const *tap_out,
+                           void *workspace, size_t workspace_bytes, ldit_stream stream, double *ms, int64_t *launches)
+{
+    if (!ms || !launches) return fail(LDIT_EINVAL, "ms / launches is null");
+    Probe probe;
+    probe.on = true;
+    probe.stream = static_cast<hipStream_t>(stream);
+    int rc = forward(cfg, packed, x, batch, tap_out, workspace, workspace_bytes, probe.stream, probe);
+    int rc2 = probe.collect(ms, launches);
+    return rc != LDIT_OK ? rc : rc2;
+}
+
+int ldit_linear_f32(const void *X, int64_t lda, const void *W, const void *bias, void *Y, int64_t ldy, int64_t M,
+                    int64_t N, int64_t K, int32_t epilogue, const void *lam, const void *R, void *Y2, ldit_stream stream)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return fail(LDIT_EINVAL, "linear: empty problem");
+    if (M * (ldy > lda ? ldy : lda) >= (1ll << 31) || N * K >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "linear: operand exceeds 2^31 elements");
+    if (ldy < N || lda < K || (ldy & 3)) return fail(LDIT_EINVAL, "linear: bad leading dimension");
+    if (!Y || !aligned16(Y) || (Y2 && !aligned16(Y2))) return fail(LDIT_EINVAL, "linear: output null or misaligned");
+    if (epilogue < LDIT_EPI_BIAS || epilogue > LDIT_EPI_SCALE_RESID) return fail(LDIT_EINVAL, "linear: unknown epilogue %d", epilogue);
+    Probe probe;
+    return linear(static_cast<const float *>(X), (int)lda, static_cast<const float *>(W), static_cast<const float *>(bias),
+                  static_cast<float *>(Y), (int)ldy, (int)M, (int)N, (int)K, epilogue, static_cast<const float *>(lam),
+                  static_cast<const float *>(R), static_cast<float *>(Y2), static_cast<hipStream_t>(stream), probe);
+}
+
+int ldit_layernorm_f32(const void *X, const void *gamma, const void *beta, void *Y, int64_t rows, int64_t C, float eps,
+                       ldit_stream stream)
+{
+    if (C > (1 << 20)) return fail(LDIT_EINVAL, "layernorm: C out of range");
+    return launch_layernorm(static_cast<const float *>(X), static_cast<const float *>(gamma), static_cast<const float *>(beta),
+                            static_cast<float *>(Y), rows, (int)C, eps, static_cast<hipStream_t>(stream));
+}
+
+int ldit_attention_f32(const void *Q, const void *K, const void *V, void *O, int64_t B, int64_t N, int64_t H, int64_t D,
+                       int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, ldit_stream stream)
+{
+    if (B <= 0 || N <= 0 || H <= 0) return fail(LDIT_EINVAL, "attention: empty problem");
+    const int64_t ldmax = ldq > ldk ? (ldq > ldv ? ldq : ldv) : (ldk > ldv ? ldk : ldv);
+    if (B * N * (ldmax > ldo ? ldmax : ldo) >= (1ll << 31) || B * H * ((N + 127) / 128) >= (1ll << 31))
+        return fail(LDIT_EUNSUPPORTED, "attention: operand exceeds 2^31 elements");
+    if (ldq < H * D || ldk < H * D || ldv < H * D || ldo < H * D) return fail(LDIT_EINVAL, "attention: row stride smaller than H*D");
+    return launch_attention(static_cast<const float *>(Q), static_cast<const float *>(K), static_cast<const float *>(V),
+                            static_cast<float *>(O), (int)B, (int)N, (int)H, (int)D, (int)ldq, (int)ldk, (int)ldv, (int)ldo,
+                            scale, static_cast<hipStream_t>(stream));
+}
+
+int ldit_embed_f32(const void *x, const void *patch_w, const void *patch_b, const void *cls, const void *pos, void *out,
+                   int64_t B, int64_t in_ch, int64_t img_h, int64_t img_w, int64_t p, int64_t C, ldit_stream stream)
+{
+    if (B <= 0 || in_ch <= 0 || img_h <= 0 || img_w <= 0 || p <= 0 || C <= 0) return fail(LDIT_EINVAL, "embed: empty problem");
+    if (img_h % p || img_w % p) return fail(LDIT_EINVAL, "embed: image %lldx%lld is not a multiple of patch %lld", (long long)img_h, (long long)img_w, (long long)p);
+    if (!x || !patch_w || !patch_b || !cls || !pos || !out) return fail(LDIT_EINVAL, "embed: null operand");
+    if (!aligned16(out) || !aligned16(pos) || (C & 3)) return fail(LDIT_EINVAL, "embed: out / pos must be 16-byte aligned, C a multiple of 4");
+    Geo g{};
+    g.C = (int)C; g.p = (int)p; g.in_ch = (int)in_ch; g.gh = (int)(img_h / p); g.gw = (int)(img_w / p);
+    g.P = g.gh * g.gw; g.T = g.P + 1; g.Kp = (int)(in_ch * p * p);
+    if (B * in_ch * img_h * img_w >= (1ll << 31) || B * g.T * C >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "embed: operand exceeds 2^31 elements");
+    Probe probe;
+    return embed(g, static_cast<const float *>(x), static_cast<const float *>(patch_w), static_cast<const float *>(patch_b),
+                 static_cast<const float *>(cls), static_cast<const float *>(pos), static_cast<float *>(out), (int)B,
+                 (int)img_h, (int)img_w, static_cast<hipStream_t>(stream), probe);
+}
+
+int ldit_tap_to_map_f32(const void *tap, void *out, int64_t B, int64_t Gh, int64_t Gw, int64_t C, float scale,
+                        ldit_stream stream)
+{
+    if (!tap || !out || !aligned16(tap)) return fail(LDIT_EINVAL, "tap_to_map: null or misaligned operand");
+    if (B * (Gh * Gw + 1) * C >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "tap_to_map: operand exceeds 2^31 elements");
+    return launch_tap_to_map(static_cast<const float *>(tap), static_cast<float *>(out), (int)B, (int)Gh, (int)Gw, (int)C,
+                             scale, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// Row LayerNorm (nn.LayerNorm over the last axis; TF:models/beit/modeling_beit.py:390-391,426,438, eps = 1e-12).
+//
+// HBM-bound: one 64-lane wave owns one row, holds it in registers (float4 per lane per 1 KiB of row), and makes the
+// two reductions (mean, then variance about the mean - never E[x^2]-E[x]^2, which cancels on BEiT's large-magnitude
+// channels) with DPP/permute wave reductions; no LDS, no second read of the row.  4 rows per 256-thread block.
+#include "ldit_common.h"
+
+namespace ldit {
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// VPL = float4 vectors per lane; handles C <= 256 * VPL
+template <int VPL>
+__global__ void __launch_bounds__(256) layernorm_rows(const float *__restrict__ X, const float *__restrict__ g,
+                                                      const float *__restrict__ b, float *__restrict__ Y, int64_t rows,
+                                                      int C, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = C >> 2;
+    const f32x4 *x4 = reinterpret_cast<const f32x4 *>(X + row * C);
+    f32x4 v[VPL];
+    float s = 0.0f;
+#pragma unroll
+    for (int u = 0; u < VPL; ++u) {
+        const int idx = lane + 64 * u;
+        if (idx < nvec) {
+            v[u] = x4[idx];
+            s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+        } else {
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float inv_c = 1.0f / (float)C;
+    const float mu = wave_sum(s) * inv_c;
+    float q = 0.0f;
+#pragma unroll
+    for (int u = 0; u < VPL; ++u) {
+        const int idx = lane + 64 * u;
+        if (idx < nvec) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[u][e] - mu;
+                v[u][e] = d;
+                q += d * d;
+            }
+        }
+    }
+    const float var = wave_sum(q) * inv_c;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g);
+    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(b);
+    f32x4 *y4 = reinterpret_cast<f32x4 *>(Y + row * C);
+#pragma unroll
+    for (int u = 0; u < VPL; ++u) {
+        const int idx = lane + 64 * u;
+        if (idx < nvec) {
+            const f32x4 gg = g4[idx], bb = b4[idx];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[u][e] * rstd * gg[e] + bb[e];
+            y4[idx] = o;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_layernorm(const float *X, const float *g, const float *b, float *Y, int64_t rows, int C, float eps,
+                     hipStream_t stream)
+{
+    if (rows <= 0 || C <= 0) return fail(LDIT_EINVAL, "layernorm: empty problem");
+    if (!X || !g || !b || !Y) return fail(LDIT_EINVAL, "layernorm: null operand");
+    if (C & 3) return fail(LDIT_EUNSUPPORTED, "layernorm: C=%d must be a multiple of 4", C);
+    if (C > 4096) return fail(LDIT_EUNSUPPORTED, "layernorm: C=%d exceeds 4096", C);
+    if (!aligned16(X) || !aligned16(Y) || !aligned16(g) || !aligned16(b)) return fail(LDIT_EINVAL, "layernorm: operands must be 16-byte aligned");
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (C <= 256) hipLaunchKernelGGL(layernorm_rows<1>, grid, block, 0, stream, X, g, b, Y, rows, C, eps);
+    else if (C <= 1024) hipLaunchKernelGGL(layernorm_rows<4>, grid, block, 0, stream, X, g, b, Y, rows, C, eps);
+    else hipLaunchKernelGGL(layernorm_rows<16>, grid, block, 0, stream, X, g, b, Y, rows, C, eps);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+}  // namespace ldit

@@ -1,0 +1,58 @@
+// Shared internals of libldit_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "ldit.h"
+
+namespace ldit {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// thread-local error text behind ldit_last_error()
+char *err_buf();
+int fail(int code, const char *fmt, ...);
+
+#define LDIT_HIP_CHECK(expr)                                                                              \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess) return ::ldit::fail(LDIT_EHIP, "%s: %s", #expr, hipGetErrorString(e__));   \
+    } while (0)
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- GEMM ----------------------------------------------------------------------------------------------------
+enum AMode { A_ROWMAJOR = 0, A_PATCH = 1 };
+enum Epi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_SCALE_RESID = 2, EPI_EMBED = 3 };
+
+struct GemmArgs {
+    const float *A;      // [M, K] row-major (A_ROWMAJOR) or the NCHW image batch (A_PATCH)
+    const float *W;      // [N, K] row-major (nn.Linear.weight)
+    float *Y;            // [M, N] (EPI_EMBED: token rows, see below)
+    float *Y2;           // optional second copy of Y (hidden-state tap)
+    const float *bias;   // [N] or null
+    const float *lam;    // [N]   (EPI_SCALE_RESID)
+    const float *R;      // [M,N] (EPI_SCALE_RESID), row stride ldy, may alias Y
+    const float *pos;    // [tokens, N] (EPI_EMBED)
+    int M, N, K;
+    int lda, ldy;        // row strides in floats
+    // A_PATCH / EPI_EMBED geometry: row m = (image b, patch gy*gw + gx); k = (ch, dy, dx)
+    int img_h, img_w, gw, patches, patch, tokens;
+};
+
+int launch_gemm(const GemmArgs &a, int epi, int amode, hipStream_t stream);
+
+// ---- other kernels ---------------------------------------------------------------------------------------------
+int launch_layernorm(const float *X, const float *g, const float *b, float *Y, int64_t rows, int C, float eps,
+                     hipStream_t stream);
+int launch_attention(const float *Q, const float *K, const float *V, float *O, int B, int N, int H, int D, int ldq,
+                     int ldk, int ldv, int ldo, float scale, hipStream_t stream);
+int launch_cls_rows(const float *cls, const float *pos, float *out, int B, int tokens, int C, hipStream_t stream);
+int launch_tap_to_map(const float *tap, float *out, int B, int Gh, int Gw, int C, float scale, hipStream_t stream);
+int launch_pack_qkv_bias(const float *bq, const float *bv, float *dst, int C, hipStream_t stream);
+
+}  // namespace ldit

@@ -1,0 +1,88 @@
+"""Data-parallel harness for the encoder forward: one process per GPU, images sharded, NO data-path collective.
+
+Inference over a batch of pages is embarrassingly parallel: every rank holds a full weight replica
+(343 MB fp32 for ViT-B - nothing against 288 GB of HBM) and a contiguous slice of the batch.  ``torch.distributed``
+(backend ``nccl`` = RCCL over xGMI on the GPU box, ``gloo`` in the CPU tests) is used only for the control plane:
+the start/stop barrier and the max-over-ranks of the measured time.  The reference has no distributed code at all
+(ref README.md:59 lists it as a TODO), so there is no NCCL call pattern to mirror.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class Rank:
+    rank: int
+    world: int
+    local_rank: int
+    backend: str
+
+    @property
+    def is_main(self) -> bool:
+        return self.rank == 0
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous ``[lo, hi)`` slice of ``total`` items owned by ``rank``; sizes differ by at most one."""
+    if not (0 <= rank < world) or total < 0:
+        raise ValueError(f"bad shard request total={total} rank={rank} world={world}")
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init(backend: str | None = None) -> Rank:
+    """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (as ``torch.distributed.run`` sets them).
+    A single process (no WORLD_SIZE, or 1) needs no process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return Rank(rank=rank, world=world, local_rank=local, backend=backend)
+
+
+def barrier(r: Rank) -> None:
+    if r.world > 1:
+        if r.backend == "nccl":
+            dist.barrier(device_ids=[r.local_rank])
+        else:
+            dist.barrier()
+
+
+def max_over_ranks(r: Rank, value: float) -> float:
+    if r.world == 1:
+        return float(value)
+    dev = torch.device("cuda", r.local_rank) if r.backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(r: Rank, value: float) -> float:
+    if r.world == 1:
+        return float(value)
+    dev = torch.device("cuda", r.local_rank) if r.backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def finalize(r: Rank) -> None:
+    if r.world > 1 and dist.is_initialized():
+        dist.destroy_process_group()

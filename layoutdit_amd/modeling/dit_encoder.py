@@ -1,0 +1,259 @@
+"""``DiTEncoder``: the ``nn.Module`` that stands where LayoutDiT puts HuggingFace's ``BeitModel``.
+
+Drop-in surface (everything the reference touches on ``DiTBackbone.dit``):
+
+* ``module(x).hidden_states[idx]`` for ``idx`` in ``[d/3, d/2, 2d/3, d]``   ref ``src/layoutdit/modeling/dit_backbone.py:47,50-52``
+* ``module.config.num_hidden_layers`` / ``.hidden_size``                     ref ``dit_backbone.py:33-36``
+* ``state_dict()`` / ``load_state_dict(strict=False)`` with BEiT key names   ref ``src/layoutdit/modeling/model.py:65-70,110-116``
+* ``.to(device)``, ``.eval()``, ``.train()``, ``parameters()``               ref ``main.py:34``, ``trainer.py:38,65``
+
+The arithmetic is NOT here: ``forward`` hands device pointers to ``ldit_vit_forward`` in ``libldit_hip.so``
+(``include/ldit.h``) on the current HIP stream.  There is no eager fallback; a CPU tensor is an error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+from ..config import DiTConfig
+from .keys import to_v4
+
+
+class _Affine(nn.Module):
+    """weight (+ optional bias) holder; the attribute path gives the tensor its BEiT key name."""
+
+    def __init__(self, *shape: int, bias: bool = True, bias_shape: Optional[Tuple[int, ...]] = None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*shape))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(*(bias_shape or (shape[0],))))
+        else:
+            self.register_parameter("bias", None)
+
+
+class _Holder(nn.Module):
+    pass
+
+
+@dataclass
+class DiTEncoderOutput:
+    """What ``BeitModel.forward`` returns, reduced to what LayoutDiT reads.  ``hidden_states`` has ``L+1`` slots;
+    slots the caller did not ask for are ``None`` (the reference only indexes ``layer_idxs``)."""
+    hidden_states: Tuple[Optional[torch.Tensor], ...]
+    last_hidden_state: Optional[torch.Tensor] = None
+    pooler_output: None = None   # BeitPooler is dead work for LayoutDiT (never read at dit_backbone.py:47)
+
+
+class DiTEncoder(nn.Module):
+    def __init__(self, config: Optional[DiTConfig] = None):
+        super().__init__()
+        self.config = config or DiTConfig()
+        cfg = self.config
+        Cc, Fm, p, ch = cfg.hidden_size, cfg.intermediate_size, cfg.patch_size, cfg.num_channels
+
+        emb = _Holder()
+        emb.cls_token = nn.Parameter(torch.zeros(1, 1, Cc))
+        emb.mask_token = nn.Parameter(torch.zeros(1, 1, Cc))           # inert: kept for key compatibility
+        emb.position_embeddings = nn.Parameter(torch.zeros(1, cfg.num_patches + 1, Cc))
+        emb.patch_embeddings = _Holder()
+        emb.patch_embeddings.projection = _Affine(Cc, ch, p, p)
+        self.embeddings = emb
+
+        self.encoder = _Holder()
+        layers = []
+        for _ in range(cfg.num_hidden_layers):
+            blk = _Holder()
+            blk.lambda_1 = nn.Parameter(torch.full((Cc,), cfg.layer_scale_init_value))
+            blk.lambda_2 = nn.Parameter(torch.full((Cc,), cfg.layer_scale_init_value))
+            blk.layernorm_before = _Affine(Cc)
+            blk.layernorm_after = _Affine(Cc)
+            blk.attention = _Holder()
+            blk.attention.attention = _Holder()
+            blk.attention.attention.query = _Affine(Cc, Cc)
+            blk.attention.attention.key = _Affine(Cc, Cc, bias=False)   # TF:models/beit/modeling_beit.py:306
+            blk.attention.attention.value = _Affine(Cc, Cc)
+            blk.attention.output = _Holder()
+            blk.attention.output.dense = _Affine(Cc, Cc)
+            blk.intermediate = _Holder()
+            blk.intermediate.dense = _Affine(Fm, Cc)
+            blk.output = _Holder()
+            blk.output.dense = _Affine(Cc, Fm)
+            layers.append(blk)
+        self.encoder.layer = nn.ModuleList(layers)
+        self.pooler = _Holder()
+        self.pooler.layernorm = _Affine(Cc)                              # inert: kept for key compatibility
+        self.reset_parameters()
+
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_key = None
+        self._workspace: Optional[torch.Tensor] = None
+        self._pos_cache: Dict[Tuple[int, int], Tuple[object, torch.Tensor]] = {}
+
+    # ---- parameters ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def reset_parameters(self) -> None:
+        """BEiT's own init (TF:models/beit/modeling_beit.py:467-482): N(0, 0.02) matrices, zero biases, LN = (1, 0)."""
+        for name, p in self.named_parameters():
+            if "lambda_" in name:
+                p.fill_(self.config.layer_scale_init_value)
+            elif "layernorm" in name:
+                p.fill_(1.0) if name.endswith("weight") else p.zero_()
+            elif name.endswith("bias") or "token" in name or "position" in name:
+                p.zero_()
+            else:
+                p.normal_(0.0, 0.02)
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """Accepts transformers-4.49 keys, 5.x keys and the detector-prefixed keys the reference saves."""
+        return super().load_state_dict({to_v4(k): v for k, v in state_dict.items()}, strict=strict, assign=assign)
+
+    @torch.no_grad()
+    def load_numpy(self, weights) -> "DiTEncoder":
+        sd = {k: torch.from_numpy(v.copy()) for k, v in weights.items()}
+        self.load_state_dict(sd, strict=True)
+        return self
+
+    # ---- packing / scratch -------------------------------------------------------------------------------------------
+    def _lcfg(self, img_h: int, img_w: int, taps: Sequence[int]) -> _lib.LditCfg:
+        cfg = self.config
+        c = _lib.LditCfg(hidden=cfg.hidden_size, layers=cfg.num_hidden_layers, heads=cfg.num_attention_heads,
+                         mlp=cfg.intermediate_size, patch=cfg.patch_size, in_ch=cfg.num_channels, img_h=img_h,
+                         img_w=img_w, n_taps=len(taps), ln_eps=cfg.layer_norm_eps, dtype=0, flags=0)
+        for i, t in enumerate(taps):
+            c.taps[i] = t
+        return c
+
+    def _position_table(self, gh: int, gw: int) -> torch.Tensor:
+        """[1+gh*gw, C] table for this grid: the parameter itself, or its bicubic resample
+        (TF:models/beit/modeling_beit.py:113-151) - host-side plumbing done once per grid and parameter version."""
+        pe = self.embeddings.position_embeddings
+        g0 = self.config.image_size // self.config.patch_size
+        if gh == g0 and gw == g0:
+            return pe.detach().reshape(-1, pe.shape[-1])
+        key = (pe.data_ptr(), pe._version, str(pe.device))
+        hit = self._pos_cache.get((gh, gw))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        with torch.no_grad():
+            Cc = pe.shape[-1]
+            patch = pe[:, 1:].reshape(1, g0, g0, Cc).permute(0, 3, 1, 2)
+            patch = F.interpolate(patch, size=(gh, gw), mode="bicubic", align_corners=False)
+            patch = patch.permute(0, 2, 3, 1).reshape(1, gh * gw, Cc)
+            table = torch.cat((pe[:, :1], patch), dim=1)[0].contiguous()
+        self._pos_cache[(gh, gw)] = (key, table)
+        return table
+
+    def _pack(self, lcfg: _lib.LditCfg, pos: torch.Tensor, device: torch.device) -> torch.Tensor:
+        params = [p for p in self.parameters()]
+        key = (str(device), lcfg.img_h, lcfg.img_w, pos.data_ptr(),
+               tuple((p.data_ptr(), p._version) for p in params))
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        lib = _lib.load()
+        for p in params:
+            if p.device != device or p.dtype != torch.float32:
+                raise ValueError("DiTEncoder parameters must be float32 on the input's GPU (call .to(device))")
+        nbytes = lib.ldit_packed_bytes(C.byref(lcfg))
+        if nbytes == 0:
+            raise _lib.LditError(_lib.LDIT_EUNSUPPORTED, lib.ldit_last_error().decode())
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        L = self.config.num_hidden_layers
+        layers = (_lib.LditLayerWeights * max(L, 1))()
+        keep = []
+
+        def ptr(t: torch.Tensor) -> int:
+            t = t.detach()
+            if not t.is_contiguous():
+                t = t.contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        for i, blk in enumerate(self.encoder.layer):
+            a = blk.attention.attention
+            lw = layers[i]
+            lw.ln1_w, lw.ln1_b = ptr(blk.layernorm_before.weight), ptr(blk.layernorm_before.bias)
+            lw.wq, lw.bq, lw.wk = ptr(a.query.weight), ptr(a.query.bias), ptr(a.key.weight)
+            lw.wv, lw.bv = ptr(a.value.weight), ptr(a.value.bias)
+            lw.wo, lw.bo = ptr(blk.attention.output.dense.weight), ptr(blk.attention.output.dense.bias)
+            lw.lam1 = ptr(blk.lambda_1)
+            lw.ln2_w, lw.ln2_b = ptr(blk.layernorm_after.weight), ptr(blk.layernorm_after.bias)
+            lw.w1, lw.b1 = ptr(blk.intermediate.dense.weight), ptr(blk.intermediate.dense.bias)
+            lw.w2, lw.b2 = ptr(blk.output.dense.weight), ptr(blk.output.dense.bias)
+            lw.lam2 = ptr(blk.lambda_2)
+        proj = self.embeddings.patch_embeddings.projection
+        w = _lib.LditWeights(patch_w=ptr(proj.weight), patch_b=ptr(proj.bias), cls=ptr(self.embeddings.cls_token),
+                             pos=ptr(pos), layer=layers)
+        _lib.check(lib.ldit_pack_weights(C.byref(lcfg), C.byref(w), packed.data_ptr(), nbytes,
+                                         torch.cuda.current_stream(device).cuda_stream))
+        self._packed, self._packed_key = packed, key
+        return packed
+
+    def _scratch(self, lcfg: _lib.LditCfg, batch: int, device: torch.device) -> torch.Tensor:
+        need = _lib.load().ldit_workspace_bytes(C.byref(lcfg), batch)
+        if need == 0:
+            raise _lib.LditError(_lib.LDIT_EUNSUPPORTED, _lib.load().ldit_last_error().decode())
+        ws = self._workspace
+        if ws is None or ws.device != device or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._workspace = ws
+        return ws
+
+    # ---- forward -------------------------------------------------------------------------------------------------
+    def forward(self, pixel_values: torch.Tensor, taps: Optional[Sequence[int]] = None,
+                _timing: Optional[dict] = None) -> DiTEncoderOutput:
+        cfg = self.config
+        if pixel_values.dim() != 4:
+            raise ValueError(f"pixel_values must be [B, C, H, W], got {tuple(pixel_values.shape)}")
+        if pixel_values.shape[1] != cfg.num_channels:
+            # same condition and wording as TF:models/beit/modeling_beit.py:84-89
+            raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the "
+                             f"configuration. Expected {cfg.num_channels} but got {pixel_values.shape[1]}.")
+        if not pixel_values.is_cuda:
+            raise RuntimeError("DiTEncoder runs only on the GPU through libldit_hip.so; move the input and the module "
+                               "to a HIP device (there is no CPU / eager fallback)")
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("DiTEncoder is forward-only in this round: freeze the backbone (the option the "
+                                      "reference keeps commented at dit_backbone.py:74-76) or run under torch.no_grad()")
+        B, _, H, W = pixel_values.shape
+        p = cfg.patch_size
+        if H % p or W % p:
+            raise ValueError(f"input {H}x{W} is not a multiple of the patch size {p}")
+        taps = list(cfg.taps if taps is None else taps)
+        if len(taps) > _lib.LDIT_MAX_TAPS:
+            raise ValueError(f"at most {_lib.LDIT_MAX_TAPS} hidden states per call")
+        device = pixel_values.device
+        x = pixel_values.detach().to(torch.float32).contiguous()   # fp16 inputs (trainer.py:155) are widened
+        with torch.no_grad(), torch.cuda.device(device):
+            lib = _lib.load()
+            gh, gw = H // p, W // p
+            lcfg = self._lcfg(H, W, taps)
+            pos = self._position_table(gh, gw)
+            packed = self._pack(lcfg, pos, device)
+            ws = self._scratch(lcfg, B, device)
+            T = gh * gw + 1
+            outs = [torch.empty((B, T, cfg.hidden_size), dtype=torch.float32, device=device) for _ in taps]
+            tap_ptrs = (C.c_void_p * max(len(outs), 1))(*[o.data_ptr() for o in outs])
+            stream = torch.cuda.current_stream(device).cuda_stream
+            if _timing is None:
+                _lib.check(lib.ldit_vit_forward(C.byref(lcfg), packed.data_ptr(), x.data_ptr(), B, tap_ptrs, ws.data_ptr(),
+                                                ws.numel(), stream))
+            else:
+                ms = (C.c_double * _lib.K_COUNT)()
+                cnt = (C.c_int64 * _lib.K_COUNT)()
+                _lib.check(lib.ldit_vit_forward_timed(C.byref(lcfg), packed.data_ptr(), x.data_ptr(), B, tap_ptrs,
+                                                      ws.data_ptr(), ws.numel(), stream, ms, cnt))
+                for i, name in enumerate(_lib.KERNEL_FAMILIES):
+                    _timing[name + "_ms"] = _timing.get(name + "_ms", 0.0) + ms[i]
+                    _timing[name + "_launches"] = _timing.get(name + "_launches", 0) + cnt[i]
+        hidden: List[Optional[torch.Tensor]] = [None] * (cfg.num_hidden_layers + 1)
+        for t, o in zip(taps, outs):
+            hidden[t] = o
+        if pixel_values.dtype != torch.float32:
+            hidden = [None if h is None else h.to(pixel_values.dtype) for h in hidden]
+        return DiTEncoderOutput(hidden_states=tuple(hidden), last_hidden_state=hidden[cfg.num_hidden_layers])

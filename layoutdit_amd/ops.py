@@ -1,0 +1,99 @@
+"""Torch-tensor front ends of the single-kernel C entry points (``include/ldit.h``).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; all arithmetic is in ``libldit_hip.so``.
+Every function requires CUDA(=HIP) fp32 contiguous tensors and raises otherwise - nothing silently runs in eager.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name}: expected a tensor on the GPU (libldit_hip has no CPU path)")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = _lib.EPI_BIAS,
+           lam: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``epilogue(x @ weight.T + bias)`` on the fp32 MFMA GEMM.  ``x``: [M, K], ``weight``: [N, K]."""
+    lib = _lib.load()
+    x, weight = _req(x, "x"), _req(weight, "weight")
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError(f"weight {tuple(weight.shape)} does not match x {tuple(x.shape)}")
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    for t, n in ((bias, "bias"), (lam, "lam"), (residual, "residual"), (out, "out"), (out2, "out2")):
+        if t is not None:
+            _req(t, n)
+    _lib.check(lib.ldit_linear_f32(_ptr(x), K, _ptr(weight), _ptr(bias), _ptr(out), N, M, N, K, epilogue, _ptr(lam),
+                                   _ptr(residual), _ptr(out2), _stream()))
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    lib = _lib.load()
+    x, gamma, beta = _req(x, "x"), _req(gamma, "gamma"), _req(beta, "beta")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    _lib.check(lib.ldit_layernorm_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), rows, C, eps, _stream()))
+    return y
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None) -> torch.Tensor:
+    """``q, k, v``: [B, N, H*D] token-major (may be column slices of one fused tensor: last-dim stride 1)."""
+    lib = _lib.load()
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if not t.is_cuda or t.dtype != torch.float32 or t.stride(-1) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+            raise ValueError(f"{n}: expected GPU float32 [B,N,H*D] with unit last stride and dense batch stride")
+    B, N, HD = q.shape
+    D = HD // heads
+    o = torch.empty((B, N, HD), device=q.device, dtype=torch.float32)
+    _lib.check(lib.ldit_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, N, heads, D, q.stride(1), k.stride(1),
+                                      v.stride(1), HD, float(D ** -0.5 if scale is None else scale), _stream()))
+    return o
+
+
+def embed(x: torch.Tensor, patch_w: torch.Tensor, patch_b: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor,
+          patch: int) -> torch.Tensor:
+    lib = _lib.load()
+    x, patch_w, patch_b = _req(x, "x"), _req(patch_w, "patch_w"), _req(patch_b, "patch_b")
+    cls, pos = _req(cls, "cls"), _req(pos, "pos")
+    B, in_ch, H, W = x.shape
+    Cc = patch_w.shape[0]
+    T = (H // patch) * (W // patch) + 1
+    out = torch.empty((B, T, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(lib.ldit_embed_f32(_ptr(x), _ptr(patch_w), _ptr(patch_b), _ptr(cls), _ptr(pos), _ptr(out), B, in_ch, H, W,
+                                  patch, Cc, _stream()))
+    return out
+
+
+def tap_to_map(tap: torch.Tensor, gh: int, gw: int, scale: float) -> torch.Tensor:
+    lib = _lib.load()
+    tap = _req(tap, "tap")
+    B, T, Cc = tap.shape
+    if T != gh * gw + 1:
+        raise ValueError(f"tap has {T} tokens, grid {gh}x{gw} needs {gh * gw + 1}")
+    out = torch.empty((B, Cc, int(gh * scale), int(gw * scale)), device=tap.device, dtype=torch.float32)
+    _lib.check(lib.ldit_tap_to_map_f32(_ptr(tap), _ptr(out), B, gh, gw, Cc, float(scale), _stream()))
+    return out

@@ -1,0 +1,63 @@
+"""The same restatement as ``vit_oracle.c`` written with plain ``torch`` CPU ops.  TEST / BASELINE INFRASTRUCTURE ONLY.
+
+Purpose: the *timed CPU baseline* of ``bench.py`` (``cpu_baseline.kind = "port"``).  The reference's CPU path is
+HuggingFace ``BeitModel`` on ATen CPU kernels (oneDNN / MKL GEMMs, ``F.scaled_dot_product_attention``); this file
+issues the very same ATen ops in the same order without importing ``transformers`` or anything from the reference,
+so its speed is the reference CPU path's speed on whatever host it runs on.  It is also checked against the golden
+vectors (tests/test_oracle_golden.py) so that it cannot drift from the C oracle.
+
+Follows TF:models/beit/modeling_beit.py:81-90,153-176,296-357,406-444,504-506 (see vit_oracle.c for the line map).
+Never imported by anything under ``layoutdit_amd/``.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _t(a) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+class TorchOracle:
+    def __init__(self, cfg, weights: Dict[str, np.ndarray]):
+        self.cfg = cfg
+        self.w = {k: _t(v) for k, v in weights.items()}
+
+    @torch.no_grad()
+    def forward(self, x, taps: Optional[Sequence[int]] = None, pos: Optional[np.ndarray] = None) -> List[torch.Tensor]:
+        cfg, w = self.cfg, self.w
+        x = x if isinstance(x, torch.Tensor) else _t(x)
+        taps = list(cfg.taps if taps is None else taps)
+        B = x.shape[0]
+        C, H = cfg.hidden_size, cfg.num_attention_heads
+        D = C // H
+        e = F.conv2d(x, w["embeddings.patch_embeddings.projection.weight"],
+                     w["embeddings.patch_embeddings.projection.bias"], stride=cfg.patch_size)
+        e = e.flatten(2).transpose(1, 2)
+        h = torch.cat((w["embeddings.cls_token"].expand(B, -1, -1), e), dim=1)
+        table = w["embeddings.position_embeddings"] if pos is None else _t(pos).unsqueeze(0)
+        h = h + table
+        out = {0: h} if 0 in taps else {}
+        for l in range(cfg.num_hidden_layers):
+            p = f"encoder.layer.{l}."
+            y = F.layer_norm(h, (C,), w[p + "layernorm_before.weight"], w[p + "layernorm_before.bias"], cfg.layer_norm_eps)
+            q = F.linear(y, w[p + "attention.attention.query.weight"], w[p + "attention.attention.query.bias"])
+            k = F.linear(y, w[p + "attention.attention.key.weight"])
+            v = F.linear(y, w[p + "attention.attention.value.weight"], w[p + "attention.attention.value.bias"])
+            q, k, v = (t.view(B, -1, H, D).transpose(1, 2) for t in (q, k, v))
+            a = F.scaled_dot_product_attention(q, k, v, scale=D ** -0.5)
+            a = a.transpose(1, 2).reshape(B, -1, C)
+            a = F.linear(a, w[p + "attention.output.dense.weight"], w[p + "attention.output.dense.bias"])
+            h = w[p + "lambda_1"] * a + h
+            y = F.layer_norm(h, (C,), w[p + "layernorm_after.weight"], w[p + "layernorm_after.bias"], cfg.layer_norm_eps)
+            m = F.linear(y, w[p + "intermediate.dense.weight"], w[p + "intermediate.dense.bias"])
+            m = F.gelu(m)
+            m = F.linear(m, w[p + "output.dense.weight"], w[p + "output.dense.bias"])
+            h = w[p + "lambda_2"] * m + h
+            if (l + 1) in taps:
+                out[l + 1] = h
+        return [out[t] for t in taps]

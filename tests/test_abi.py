@@ -1,0 +1,131 @@
+"""CPU-only checks of the drop-in boundary: libldit_hip.so loads, exports every symbol include/ldit.h declares,
+its host-side sizing / validation logic behaves, and the Python mirror has the reference's module surface.
+No kernel is launched here (there is no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from layoutdit_amd import _lib, config as cfgs, synth
+from layoutdit_amd.modeling import DiTBackbone, DiTEncoder
+from layoutdit_amd.modeling.keys import remap_state_dict, to_v4, to_v5
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "ldit.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ldit_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared_functions()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/ldit.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names           # the ctypes table covers the header exactly
+    assert lib.ldit_abi_version() == _lib.LDIT_ABI_VERSION
+
+
+def _cfg(c, h=224, w=224, taps=None):
+    taps = list(c.taps if taps is None else taps)
+    lc = _lib.LditCfg(hidden=c.hidden_size, layers=c.num_hidden_layers, heads=c.num_attention_heads,
+                      mlp=c.intermediate_size, patch=c.patch_size, in_ch=3, img_h=h, img_w=w, n_taps=len(taps),
+                      ln_eps=1e-12, dtype=0, flags=0)
+    for i, t in enumerate(taps):
+        lc.taps[i] = t
+    return lc
+
+
+def test_sizing_is_host_side_and_consistent():
+    lib = _lib.load()
+    base = cfgs.vit_base()
+    lc = _cfg(base)
+    n_params = sum(int(np.prod(s)) for k, s in synth.param_shapes(base).items()
+                   if "mask_token" not in k and "pooler" not in k)
+    # packed block = every parameter the path reads + the C zeros of the absent key bias per layer
+    assert lib.ldit_packed_bytes(C.byref(lc)) == 4 * (n_params + base.num_hidden_layers * base.hidden_size)
+    M = 64 * 197
+    assert lib.ldit_workspace_bytes(C.byref(lc), 64) >= 4 * M * (768 + 768 + 3072)
+    assert lib.ldit_workspace_bytes(C.byref(lc), 0) == 0
+
+
+@pytest.mark.parametrize("mutate,fragment", [
+    (lambda c: setattr(c, "heads", 7), "divisible"),
+    (lambda c: setattr(c, "heads", 24), "head_dim"),
+    (lambda c: setattr(c, "img_h", 230), "multiple of patch"),
+    (lambda c: setattr(c, "n_taps", 9), "n_taps"),
+    (lambda c: setattr(c, "dtype", 5), "dtype"),
+])
+def test_bad_geometry_is_rejected_with_a_message(mutate, fragment):
+    lib = _lib.load()
+    lc = _cfg(cfgs.vit_base())
+    mutate(lc)
+    assert lib.ldit_packed_bytes(C.byref(lc)) == 0
+    assert fragment in lib.ldit_last_error().decode()
+
+
+def test_null_and_misaligned_arguments_fail_before_any_launch():
+    lib = _lib.load()
+    lc = _cfg(cfgs.vit_base())
+    rc = lib.ldit_vit_forward(C.byref(lc), None, None, 1, None, None, 0, None)
+    assert rc == _lib.LDIT_EINVAL
+    rc = lib.ldit_linear_f32(None, 32, None, None, None, 32, 4, 4, 32, 0, None, None, None, None)
+    assert rc == _lib.LDIT_EINVAL
+    rc = lib.ldit_linear_f32(16, 40, 16, None, 16, 8, 8, 8, 40, 0, None, None, None, None)   # K % 32 != 0
+    assert rc == _lib.LDIT_EUNSUPPORTED and b"multiple of 32" in lib.ldit_last_error()
+    rc = lib.ldit_attention_f32(16, 16, 16, 16, 1, 8, 1, 32, 32, 32, 32, 32, 1.0, None)       # head_dim 32
+    assert rc == _lib.LDIT_EUNSUPPORTED
+
+
+def test_module_surface_matches_what_the_reference_touches():
+    cfg = cfgs.vit_tiny()
+    m = DiTEncoder(cfg)
+    assert m.config.num_hidden_layers == 12 and m.config.hidden_size == 192        # ref dit_backbone.py:33-36
+    sd = m.state_dict()
+    assert set(sd) == set(synth.param_shapes(cfg))                                   # transformers-4.49 key names
+    assert not any(k.endswith("attention.attention.key.bias") for k in sd)           # TF:306
+    for k, shape in synth.param_shapes(cfg).items():
+        assert tuple(sd[k].shape) == shape, k
+    bb = DiTBackbone(config=cfg)
+    assert bb.layer_idxs == [4, 6, 8, 12] and bb.scales == [4.0, 2.0, 1.0, 0.5] and bb.hidden_size == 192
+    assert all(k.startswith("dit.") for k in bb.state_dict())
+    with pytest.raises(ValueError, match="hub"):
+        DiTBackbone(pretrained=True)
+
+
+def test_state_dict_layouts_round_trip():
+    cfg = cfgs.vit_micro()
+    w = synth.synth_weights(cfg, 3)
+    v5 = {to_v5(k): torch.from_numpy(v) for k, v in w.items()}
+    assert "layers.1.attention.q_proj.weight" in v5 and "layers.2.mlp.fc2.bias" in v5
+    assert {to_v4(k) for k in v5} == set(w)
+    m = DiTEncoder(cfg)
+    res = m.load_state_dict(v5, strict=True)                                         # 5.x names
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in w.items():
+        np.testing.assert_array_equal(m.state_dict()[k].numpy(), v)
+    saved = {"model.backbone.backbone.dit." + k: v for k, v in m.state_dict().items()}   # ref model.py:110-116
+    m2 = DiTEncoder(cfg)
+    res = m2.load_state_dict(saved, strict=False)                                    # ref model.py:65-70
+    assert not res.missing_keys
+    assert set(remap_state_dict(saved)) == set(w)
+
+
+def test_cpu_input_fails_loudly_instead_of_falling_back():
+    m = DiTEncoder(cfgs.vit_micro())
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(ValueError, match="channel dimension"):
+        m(torch.zeros(1, 1, 64, 64))
+
+
+def test_flops_formula_matches_baseline_md():
+    assert cfgs.vit_base().flops_per_image() == 2 * 17_563_060_224
+    assert cfgs.vit_tiny().flops_per_image() == 2 * 1_253_491_200
+    assert cfgs.vit_large().flops_per_image(512, 512) == 2 * 361_985_261_568

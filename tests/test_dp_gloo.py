@@ -1,0 +1,66 @@
+"""Multi-process (world_size 2, gloo, CPU) check of the data-parallel harness bench.py uses at N > 1:
+shards tile the global batch exactly, each rank's synthetic shard equals the same rows of the global batch, and the
+control-plane reductions (barrier, max of times, sum of counts) agree on every rank.  No GPU, no data-path collective."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from layoutdit_amd import dp, synth
+
+
+def test_shard_range_tiles_the_batch():
+    for total in (0, 1, 7, 64, 65, 513):
+        for world in (1, 2, 3, 8):
+            edges = [dp.shard_range(total, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        dp.shard_range(8, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r = dp.init(backend="gloo")
+    try:
+        per_rank = 3                                    # weak scaling: fixed images per rank
+        lo, hi = dp.shard_range(per_rank * world, r.rank, r.world)
+        x = synth.synth_images(hi - lo, 32, 32, seed=1234, first_index=lo)
+        dp.barrier(r)
+        t = dp.max_over_ranks(r, 1.0 + r.rank)          # slowest rank defines the step time
+        n = dp.sum_over_ranks(r, float(hi - lo))
+        q.put((r.rank, lo, hi, float(x.astype(np.float64).sum()), t, n, r.is_main))
+    finally:
+        dp.finalize(r)
+
+
+def test_two_ranks_over_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = synth.synth_images(6, 32, 32, seed=1234)
+    for rank, lo, hi, s, t, n, is_main in got:
+        assert (lo, hi) == (3 * rank, 3 * rank + 3)
+        assert abs(s - float(full[lo:hi].astype(np.float64).sum())) < 1e-9    # shard == rows of the global batch
+        assert t == 2.0 and n == 6.0
+        assert is_main == (rank == 0)

@@ -1,0 +1,205 @@
+"""Per-kernel parity on the GPU: each HIP kernel, called through the C ABI (ctypes, include/ldit.h), against the CPU
+oracle on the same seeded inputs and against the golden per-op vectors.
+
+Tolerances (fp32, written per test): the north-star gate is 1e-3 relative; the kernels are exact-fp32 MFMA so the
+gates here are 100x tighter (relative-L2 <= 1e-5, element-wise <= 1e-5 * max(|ref|, 1))."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from layoutdit_amd import _lib, ops, synth          # noqa: E402
+from oracle import oracle                           # noqa: E402
+from tests.golden.kat_inputs import attn_inputs, ln_inputs  # noqa: E402
+from tests.util import max_rel, rel_l2              # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+
+
+def _rand(seed, *shape, scale=1.0):
+    n = int(np.prod(shape))
+    return (scale * synth.normal(seed, 7, n)).astype(np.float32).reshape(shape)
+
+
+@pytest.fixture(autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "gpu-marked test running without a GPU"
+    _lib.load()
+    yield
+    os.environ.pop("LDIT_GEMM_TILE", None)
+
+
+# ---------------------------------------------------------------------------------------------------------- GEMM
+GEMM_SHAPES = [
+    (37, 50, 96),        # ragged in M and N, smaller than any tile
+    (394, 576, 192),     # ViT-Tiny qkv at bs=2
+    (34, 64, 64),        # micro
+    (1000, 768, 768),    # o_proj-like
+    (513, 3072, 768),    # fc1-like, ragged M
+    (321, 768, 3072),    # fc2-like, one row past a 320-row tile
+]
+
+
+@pytest.mark.parametrize("tile", ["auto", "0", "1", "2"])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_linear_bias(M, N, K, tile):
+    if tile != "auto":
+        os.environ["LDIT_GEMM_TILE"] = tile
+    x, w, b = _rand(1, M, K), _rand(2, N, K, scale=0.05), _rand(3, N, scale=0.1)
+    y = ops.linear(_dev(x), _dev(w), _dev(b)).cpu().numpy()
+    ref = oracle.linear(x, w, b)
+    assert rel_l2(y, ref) < 1e-5
+    assert max_rel(y, ref) < 1e-5
+
+
+def test_linear_no_bias_matches_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_ops.npz"))
+    y = ops.linear(_dev(g["lin_x"]), _dev(g["lin_w"]), _dev(g["lin_b"])).cpu().numpy()
+    assert rel_l2(y, g["lin_y"]) < 1e-6
+    x, w = _rand(4, 130, 64), _rand(5, 70, 64)
+    assert rel_l2(ops.linear(_dev(x), _dev(w)).cpu().numpy(), oracle.linear(x, w)) < 1e-5
+
+
+def test_linear_identity_asymmetric():
+    """A = I against an asymmetric W catches a transposed or row-permuted C/D register map."""
+    K = 128
+    w = (np.arange(96 * K, dtype=np.float32).reshape(96, K) % 251) - 100.0
+    eye = np.eye(K, dtype=np.float32)
+    y = ops.linear(_dev(eye), _dev(w)).cpu().numpy()
+    np.testing.assert_array_equal(y, w.T)
+
+
+@pytest.mark.parametrize("tile", ["0", "1", "2"])
+def test_linear_gelu_epilogue(tile):
+    os.environ["LDIT_GEMM_TILE"] = tile
+    M, N, K = 333, 320, 96
+    x, w, b = _rand(6, M, K), _rand(7, N, K, scale=0.2), _rand(8, N)
+    y = ops.linear(_dev(x), _dev(w), _dev(b), epilogue=_lib.EPI_BIAS_GELU).cpu().numpy()
+    ref = oracle.gelu(oracle.linear(x, w, b))
+    np.testing.assert_allclose(y, ref, rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("tile", ["0", "1", "2"])
+def test_linear_scale_residual_inplace_and_tap(tile):
+    """h <- h + lam * (x W^T + b), updated IN PLACE (R aliases Y) with a second copy to the tap buffer."""
+    os.environ["LDIT_GEMM_TILE"] = tile
+    M, N, K = 197 * 2, 192, 768
+    x, w, b = _rand(9, M, K), _rand(10, N, K, scale=0.05), _rand(11, N, scale=0.1)
+    lam, r = np.abs(_rand(12, N)) * 0.3 + 0.05, _rand(13, M, N)
+    h = _dev(r)
+    tap = torch.full((M, N), float("nan"), device=DEV)
+    out = ops.linear(_dev(x), _dev(w), _dev(b), epilogue=_lib.EPI_SCALE_RESID, lam=_dev(lam), residual=h, out=h, out2=tap)
+    ref = (r.astype(np.float64) + lam.astype(np.float64) * oracle.linear(x, w, b).astype(np.float64)).astype(np.float32)
+    assert out.data_ptr() == h.data_ptr()
+    assert rel_l2(h.cpu().numpy(), ref) < 1e-6
+    np.testing.assert_array_equal(tap.cpu().numpy(), h.cpu().numpy())
+
+
+def test_linear_rejects_bad_arguments():
+    x, w = _dev(_rand(1, 8, 40)), _dev(_rand(2, 8, 40))
+    with pytest.raises(_lib.LditError) as e:        # K not a multiple of 32
+        ops.linear(x, w)
+    assert e.value.code == _lib.LDIT_EUNSUPPORTED
+    with pytest.raises(ValueError):
+        ops.linear(torch.zeros(4, 32), torch.zeros(4, 32))   # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------------------------------ LayerNorm
+def test_layernorm_golden_rows(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_ops.npz"))
+    x, gam, bet = ln_inputs()
+    y = ops.layernorm(_dev(x), _dev(gam), _dev(bet), eps=1e-12).cpu().numpy()
+    ref64 = oracle.layernorm(x, gam, bet, eps=1e-12)
+    tight = [r for r in range(16) if r not in (1, 3)]     # rows 1 and 3 are ill-conditioned in fp32 by construction
+    assert max_rel(y[tight], g["ln_y"][tight]) < 2e-5
+    assert max_rel(y[tight], ref64[tight]) < 2e-5
+    assert rel_l2(y[1], ref64[1]) < 5e-2
+    assert np.all(np.isfinite(y))
+
+
+@pytest.mark.parametrize("rows,C", [(1, 64), (5, 192), (394, 768), (1025, 1024), (3, 2048)])
+def test_layernorm_shapes(rows, C):
+    x = _rand(20, rows, C, scale=3.0) + 1.5
+    gam, bet = 1.0 + 0.1 * _rand(21, C), 0.1 * _rand(22, C)
+    y = ops.layernorm(_dev(x), _dev(gam), _dev(bet), eps=1e-12).cpu().numpy()
+    assert max_rel(y, oracle.layernorm(x, gam, bet, eps=1e-12)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("n_tok", [197, 1025])
+def test_attention_golden(golden_dir, n_tok):
+    g = np.load(os.path.join(golden_dir, "g4_ops.npz"))
+    q, k, v = attn_inputs(n_tok)
+    o = ops.attention(_dev(q), _dev(k), _dev(v), heads=3).cpu().numpy()
+    assert rel_l2(o, g[f"attn{n_tok}_o"]) < 1e-5
+    assert max_rel(o, g[f"attn{n_tok}_o"]) < 1e-5
+    assert rel_l2(o, oracle.attention(q, k, v, heads=3)) < 1e-5
+
+
+@pytest.mark.parametrize("B,N,H", [(1, 1, 1), (2, 17, 2), (1, 32, 1), (1, 33, 3), (3, 224, 2), (2, 225, 1), (1, 449, 2)])
+def test_attention_ragged_lengths(B, N, H):
+    """Token counts on and around the 32-key tile and the 224-key LDS chunk boundaries."""
+    D = 64
+    q, k, v = _rand(30, B, N, H * D), _rand(31, B, N, H * D), _rand(32, B, N, H * D)
+    o = ops.attention(_dev(q), _dev(k), _dev(v), heads=H).cpu().numpy()
+    assert rel_l2(o, oracle.attention(q, k, v, heads=H)) < 1e-5
+
+
+def test_attention_on_fused_qkv_views():
+    """The forward feeds column slices of the fused [M, 3C] projection (row stride 3C)."""
+    B, N, H, D = 2, 197, 3, 64
+    qkv = _rand(33, B, N, 3 * H * D)
+    t = _dev(qkv)
+    C_ = H * D
+    o = ops.attention(t[..., :C_], t[..., C_:2 * C_], t[..., 2 * C_:], heads=H).cpu().numpy()
+    ref = oracle.attention(qkv[..., :C_], qkv[..., C_:2 * C_], qkv[..., 2 * C_:], heads=H)
+    assert rel_l2(o, ref) < 1e-5
+
+
+def test_attention_large_logits_force_rescale():
+    """A dominant key placed in the LAST chunk makes the running max jump at the final rescale (N = 449: 3 chunks)."""
+    B, N, H, D = 1, 449, 1, 64
+    q, k, v = _rand(34, B, N, D), _rand(35, B, N, D), _rand(36, B, N, D)
+    k[0, 440] = 6.0 * q[0, 7]
+    q[0, 7] *= 3.0
+    o = ops.attention(_dev(q), _dev(k), _dev(v), heads=H).cpu().numpy()
+    assert max_rel(o, oracle.attention(q, k, v, heads=H)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------- embedding / maps
+@pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 64), (2, 224, 224, 192), (1, 96, 160, 128)])
+def test_embed(B, H, W, C):
+    x = synth.synth_images(B, H, W, seed=5, kind="uniform")
+    pw, pb = _rand(40, C, 3, 16, 16, scale=0.02), _rand(41, C, scale=0.02)
+    T = (H // 16) * (W // 16) + 1
+    cls, pos = _rand(42, C, scale=0.02), _rand(43, T, C, scale=0.02)
+    out = ops.embed(_dev(x), _dev(pw), _dev(pb), _dev(cls), _dev(pos), 16).cpu().numpy()
+    ref = np.empty((B, T, C), np.float32)
+    oracle.lib().oracle_embed(x.ctypes.data, pw.ctypes.data, pb.ctypes.data, cls.ctypes.data, pos.ctypes.data, B, 3, H, W,
+                              16, C, ref.ctypes.data)
+    assert rel_l2(out, ref) < 1e-5
+    assert max_rel(out, ref) < 1e-5
+
+
+def test_tap_to_map_golden(golden_dir):
+    g5 = np.load(os.path.join(golden_dir, "g5_maps.npz"))
+    g0 = np.load(os.path.join(golden_dir, "g0_micro.npz"))
+    for i, (idx, scale) in enumerate(zip([1, 1, 2, 3], [4.0, 2.0, 1.0, 0.5]), start=2):
+        m = ops.tap_to_map(_dev(g0["hidden"][idx]), 4, 4, scale).cpu().numpy()
+        assert m.shape == g5[f"micro_p{i}"].shape
+        assert max_rel(m, g5[f"micro_p{i}"]) < 1e-6
+
+
+@pytest.mark.parametrize("scale", [4.0, 2.0, 1.0, 0.5])
+def test_tap_to_map_vs_oracle(scale):
+    tap = _rand(50, 2, 14 * 14 + 1, 192)
+    m = ops.tap_to_map(_dev(tap), 14, 14, scale).cpu().numpy()
+    assert max_rel(m, oracle.tap_to_map(tap, 14, 14, scale)) < 1e-6
