@@ -127,7 +127,7 @@ int ldit_vit_forward_timed(const ldit_cfg *cfg, const void *packed, const void *
 
 /* ---- the kernels, one entry point each (unit parity tests; also usable on their own) -------------------------- */
 
-/* Y[M,N] = epilogue(X[M,K] . W[N,K]^T).  fp32 MFMA.  K % 32 == 0, lda/ldy % 4 == 0.
+/* Y[M,N] = epilogue(X[M,K] . W[N,K]^T).  fp32 MFMA.  K % 32 == 0, lda % 4 == 0.
  * bias[N] may be NULL (= 0).  lam[N], R[M,N] (row stride ldy) only for LDIT_EPI_SCALE_RESID; R may alias Y.
  * Y2 (optional, same shape/stride as Y) receives a second copy of the result (hidden-state tap). */
 int ldit_linear_f32(const void *X, int64_t lda, const void *W, const void *bias, void *Y, int64_t ldy, int64_t M,

@@ -335,7 +335,7 @@ int ldit_linear_f32(const void *X, int64_t lda, const void *W, const void *bias,
 {
     if (M <= 0 || N <= 0 || K <= 0) return fail(LDIT_EINVAL, "linear: empty problem");
     if (M * (ldy > lda ? ldy : lda) >= (1ll << 31) || N * K >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "linear: operand exceeds 2^31 elements");
-    if (ldy < N || lda < K || (ldy & 3)) return fail(LDIT_EINVAL, "linear: bad leading dimension");
+    if (ldy < N || lda < K) return fail(LDIT_EINVAL, "linear: bad leading dimension");
     if (!Y || !aligned16(Y) || (Y2 && !aligned16(Y2))) return fail(LDIT_EINVAL, "linear: output null or misaligned");
     if (epilogue < LDIT_EPI_BIAS || epilogue > LDIT_EPI_SCALE_RESID) return fail(LDIT_EINVAL, "linear: unknown epilogue %d", epilogue);
     Probe probe;
