@@ -32,7 +32,88 @@ __device__ __forceinline__ void glds16(const float *gsrc, char *lds_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// erf to < 1 ulp in ~25 instructions, branch-free (both ranges evaluated, one selected): odd polynomial in x below
+// 0.927734375, 1 - exp(poly(|x|)) above (coefficients: N. Juffa's single-precision erff).  libdevice's erff costs
+// ~90 instructions per call with divergent ranges - 28 us per fc1 tile round when it sat in the epilogue.
+__device__ __forceinline__ float erf_fast(float a)
+{
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    const float big = copysignf(1.0f - __expf(r), a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    const float small = fmaf(q, a, a);
+    return t > 0.927734375f ? big : small;
+}
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f)); }
+
+// Epilogue of one wave: register r of lanes 0-31 / 32-63 = 128 contiguous bytes of output rows 8(r>>2)+(r&3) / +4 of
+// each 32x32 tile.  CHECK = false for blocks wholly inside the matrix: no per-element bounds work at all.
+// Addressing is a uniform base pointer + a 32-bit per-lane index (one v_add per element).  The residual loads of tile
+// t+1 are issued before the stores of tile t and fenced with compiler barriers: left alone, hipcc hoists all
+// TM*TN*16 residual loads (and their 64-bit addresses) to the top and spills them to scratch (72k cycles per block).
+template <int TM, int TN, int EPI, bool CHECK, bool DUAL>
+__device__ __forceinline__ void store_tile(const GemmArgs &p, const f32x16 (&acc)[TM][TN], int mw, int nw)
+{
+    constexpr int NT = TM * TN;
+    const unsigned ldy = (unsigned)p.ldy;
+    const unsigned lane_base = (unsigned)mw * ldy + (unsigned)nw;
+    float resid[2][16];
+    auto fetch = [&](int t, float(&dst)[16]) {
+        const int i = t % TM, j = t / TM;
+        const int n = nw + j * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mw + i * 32 + 8 * (r >> 2) + (r & 3);
+            const unsigned idx = lane_base + (unsigned)(i * 32 + 8 * (r >> 2) + (r & 3)) * ldy + (unsigned)(j * 32);
+            dst[r] = (!CHECK || (n < p.N && m < p.M)) ? p.R[idx] : 0.0f;
+        }
+    };
+    if (EPI == EPI_SCALE_RESID) fetch(0, resid[0]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (EPI == EPI_SCALE_RESID) {
+            if (t + 1 < NT) fetch(t + 1, resid[(t + 1) & 1]);
+            asm volatile("" ::: "memory");
+        }
+        const int i = t % TM, j = t / TM;
+        const int n = nw + j * 32;
+        const bool nok = !CHECK || n < p.N;
+        const float bias = (nok && p.bias) ? p.bias[n] : 0.0f;
+        float lam = 0.0f;
+        if (EPI == EPI_SCALE_RESID) lam = nok ? p.lam[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mw + i * 32 + 8 * (r >> 2) + (r & 3);
+            if (CHECK && (!nok || m >= p.M)) continue;
+            float v = acc[i][j][r] + bias;
+            unsigned o;
+            if (EPI == EPI_EMBED) {
+                const int b = m / p.patches, pi = m - b * p.patches;
+                v += p.pos[(unsigned)(1 + pi) * (unsigned)p.N + (unsigned)n];
+                o = ((unsigned)b * p.tokens + 1 + pi) * ldy + (unsigned)n;
+            } else {
+                o = lane_base + (unsigned)(i * 32 + 8 * (r >> 2) + (r & 3)) * ldy + (unsigned)(j * 32);
+                if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
+                if (EPI == EPI_SCALE_RESID) v = resid[t & 1][r] + lam * v;
+            }
+            p.Y[o] = v;
+            if (DUAL) p.Y2[o] = v;
+        }
+        if (EPI == EPI_SCALE_RESID) asm volatile("" ::: "memory");
+    }
+}
 
 template <int TM, int TN, int EPI, int AMODE>
 __global__ void __launch_bounds__(256) gemm_f32_mfma(const GemmArgs p)
@@ -46,6 +127,11 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(const GemmArgs p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
+#ifdef LDIT_GEMM_STAMPS
+    // diagnostic build only (never shipped in libldit_hip.so): wall/cycle stamps of the block's phases
+    unsigned long long st_real0 = __builtin_amdgcn_s_memrealtime(), st_clk0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st_clk1 = 0, st_clk2 = 0;
+#endif
 
     // ---- block -> tile (XCD-aware, bijective) ------------------------------------------------------------------
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
@@ -111,60 +197,132 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(const GemmArgs p)
 
     const int sw = (li >> 1) & 7;
     const int nk = p.K / BK;
+    const int a_row = (wm * TM * 32 + li) * ROW_BYTES, b_row = (BM + wn * TN * 32 + li) * ROW_BYTES;
+
+    // fragment of 8-deep chunk kc of a stage: lane half lh takes k = 8kc+4lh .. +3 as one (swizzled) b128 per 32-row tile
+    auto load_frags = [&](int stage, int kc, f32x4(&a)[TM], f32x4(&b)[TN]) {
+        const char *base = smem + stage * (ROWS * ROW_BYTES) + ((kc * 2 + lh) ^ sw) * 16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4 *>(base + a_row + i * 32 * ROW_BYTES);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4 *>(base + b_row + j * 32 * ROW_BYTES);
+    };
+    auto mfma_chunk = [&](const f32x4(&a)[TM], const f32x4(&b)[TN]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    };
+
+    // Software pipeline (one basic block per k-tile, instruction order pinned with sched_group_barrier):
+    //   * fragments of chunk c+1 are read from LDS while the 4*TM*TN MFMAs of chunk c execute;
+    //   * the NLD LDS-DMA pieces of tile kt+1 are dribbled out one per two MFMAs of chunk 0 - issued back to back
+    //     they cost ~60 cycles each with the matrix pipe idle (measured: 0.5 us of a 4.8 us k-tile);
+    //   * the k-tile hand-over barrier sits in front of the LAST chunk's MFMAs, whose operands are already in
+    //     registers, so neither an LDS latency nor the barrier drains the matrix pipe.
+    // The body is branch-free: the last iteration re-fetches the last tile into the idle stage (drained by the final
+    // hand-over's vmcnt(0)) and re-reads fragments it never uses.
+    constexpr int SG_MFMA = 0x8, SG_VMEM = 0x20, SG_DSR = 0x100;
+    constexpr int NM = 4 * TM * TN, NF = TM + TN;
+    constexpr int MPD = (NM - NF) / NLD;       // MFMAs issued per DMA piece in chunk 0 (0: tile too small to interleave)
+    static_assert(NF <= NM, "fewer MFMAs than fragment reads in a chunk");
+    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
     issue(0, 0);
+    __syncthreads();
+#ifdef LDIT_GEMM_STAMPS
+    st_clk1 = __builtin_amdgcn_s_memtime();
+#endif
+    load_frags(0, 0, fa0, fb0);
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();   // drains this wave's DMA (vmcnt 0), then every wave has finished reading the other stage
-        if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * BK);
-        const char *As = smem + (kt & 1) * (ROWS * ROW_BYTES) + (wm * TM * 32 + li) * ROW_BYTES;
-        const char *Bs = smem + (kt & 1) * (ROWS * ROW_BYTES) + (BM + wn * TN * 32 + li) * ROW_BYTES;
+        const int cur = kt & 1;
+        const int knext = (kt + 1 < nk ? kt + 1 : nk - 1) * BK;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- chunk 0: MFMAs of f0 | read chunk 1 -> f1 | DMA tile kt+1 -> stage cur^1 (free since the last hand-over)
+        load_frags(cur, 1, fa1, fb1);
+        issue(cur ^ 1, knext);
+        mfma_chunk(fa0, fb0);
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            const int off = ((kc * 2 + lh) ^ sw) * 16;
-            f32x4 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4 *>(As + i * 32 * ROW_BYTES + off);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * ROW_BYTES + off);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        for (int g = 0; g < NF; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 0);
         }
+        if (MPD > 0) {
+#pragma unroll
+            for (int g = 0; g < NLD; ++g) {
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, MPD, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF - MPD * NLD, 0);
+        } else {
+            __builtin_amdgcn_sched_group_barrier(SG_VMEM, NLD, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- chunk 1: MFMAs of f1 | read chunk 2 -> f0
+        load_frags(cur, 2, fa0, fb0);
+        mfma_chunk(fa1, fb1);
+#pragma unroll
+        for (int g = 0; g < NF; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- chunk 2: MFMAs of f0 | read chunk 3 -> f1
+        load_frags(cur, 3, fa1, fb1);
+        mfma_chunk(fa0, fb0);
+#pragma unroll
+        for (int g = 0; g < NF; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 2);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 2);
+        }
+        __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- hand-over: own DMA landed (vmcnt 0), own reads of stage cur done (lgkmcnt 0), then all waves
+        __syncthreads();
+        // ---- chunk 3: MFMAs of f1 | read chunk 0 of the next stage -> f0
+        load_frags(cur ^ 1, 0, fa0, fb0);
+        mfma_chunk(fa1, fb1);
+#pragma unroll
+        for (int g = 0; g < NF; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 3);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 3);
+        }
+        __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF, 3);
     }
 
+#ifdef LDIT_GEMM_STAMPS
+    st_clk2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue ---------------------------------------------------------------------------------------------------
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * TN * 32 + j * 32 + li;
-        const bool nok = n < p.N;
-        const float bias = (nok && p.bias) ? p.bias[n] : 0.0f;
-        float lam = 0.0f;
-        if (EPI == EPI_SCALE_RESID) lam = nok ? p.lam[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * TM * 32 + i * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
-                if (!nok || m >= p.M) continue;
-                float v = acc[i][j][r] + bias;
-                size_t o;
-                if (EPI == EPI_EMBED) {
-                    const int b = m / p.patches, pi = m - b * p.patches;
-                    v += p.pos[(size_t)(1 + pi) * p.N + n];
-                    o = ((size_t)b * p.tokens + 1 + pi) * p.ldy + n;
-                } else {
-                    o = (size_t)m * p.ldy + n;
-                    if (EPI == EPI_BIAS_GELU) v = gelu_erf(v);
-                    if (EPI == EPI_SCALE_RESID) v = p.R[o] + lam * v;
-                }
-                p.Y[o] = v;
-                if (p.Y2) p.Y2[o] = v;
-            }
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);    // block-uniform
+    const int mw = m0 + wm * TM * 32 + 4 * lh, nw = n0 + wn * TN * 32 + li;
+    if (interior) {
+        if (p.Y2) store_tile<TM, TN, EPI, false, true>(p, acc, mw, nw);
+        else store_tile<TM, TN, EPI, false, false>(p, acc, mw, nw);
+    } else {
+        if (p.Y2) store_tile<TM, TN, EPI, true, true>(p, acc, mw, nw);
+        else store_tile<TM, TN, EPI, true, false>(p, acc, mw, nw);
+    }
+#ifdef LDIT_GEMM_STAMPS
+    if (p.stamps) {
+        const unsigned long long st_clk3 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st_clk4 = __builtin_amdgcn_s_memtime(), st_real1 = __builtin_amdgcn_s_memrealtime();
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (tid == 0) {
+            unsigned long long *o = p.stamps + (size_t)blockIdx.x * 8;
+            o[0] = st_real0; o[1] = st_real1; o[2] = st_clk1 - st_clk0; o[3] = st_clk2 - st_clk1; o[4] = st_clk3 - st_clk2;
+            o[5] = st_clk4 - st_clk3; o[6] = ((unsigned long long)xcc << 32) | hwid; o[7] = tile;
         }
     }
+#endif
 }
 
 template <int TM, int TN, int EPI, int AMODE>
@@ -212,6 +370,18 @@ int launch_tiled(const GemmArgs &a, hipStream_t stream)
 }
 
 }  // namespace
+
+#ifdef LDIT_GEMM_STAMPS
+extern "C" int ldit_dbg_linear_stamps(const void *X, const void *W, const void *bias, void *Y, int M, int N, int K, int epi,
+                                      const void *lam, const void *R, void *stamps, void *stream)
+{
+    GemmArgs a{};
+    a.A = (const float *)X; a.W = (const float *)W; a.Y = (float *)Y; a.bias = (const float *)bias;
+    a.lam = (const float *)lam; a.R = (const float *)R; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldy = N;
+    a.stamps = (unsigned long long *)stamps;
+    return launch_gemm(a, epi, A_ROWMAJOR, (hipStream_t)stream);
+}
+#endif
 
 int launch_gemm(const GemmArgs &a, int epi, int amode, hipStream_t stream)
 {

@@ -42,6 +42,9 @@ struct GemmArgs {
     int lda, ldy;        // row strides in floats
     // A_PATCH / EPI_EMBED geometry: row m = (image b, patch gy*gw + gx); k = (ch, dy, dx)
     int img_h, img_w, gw, patches, patch, tokens;
+#ifdef LDIT_GEMM_STAMPS
+    unsigned long long *stamps;   // diagnostic build only: 8 words per block (see scripts/gemm_stamps.py)
+#endif
 };
 
 int launch_gemm(const GemmArgs &a, int epi, int amode, hipStream_t stream);
