@@ -114,3 +114,21 @@ def test_g5_tap_maps(golden_dir):
         ref = g5[f"micro_p{i}"]
         assert m.shape == ref.shape
         assert max_rel(m, ref) < 1e-6, i
+
+
+def test_torch_restatement_matches_c_oracle_and_golden(golden_dir):
+    """oracle/vit_oracle_torch.py (the timed CPU baseline) is the same function as the C oracle."""
+    import torch
+    from oracle.vit_oracle_torch import TorchOracle
+    g = _load(golden_dir, "g1_tiny.npz")
+    cfg = cfgs.vit_tiny()
+    w = synth.synth_weights(cfg, seed=int(g["seeds"][0]))
+    x = synth.synth_images(2, 224, 224, seed=int(g["seeds"][1]))
+    torch.set_num_threads(4)
+    taps = TorchOracle(cfg, w).forward(x)
+    ref, _ = oracle.vit_forward(cfg, w, x)
+    stride = int(g["stride"][0])
+    for t, a, r in zip(cfg.taps, taps, ref):
+        a = a.numpy()
+        assert rel_l2(a, r) < 2e-5
+        assert rel_l2(a.reshape(-1)[::stride], g[f"tap{t}_sample"]) < 1e-5
