@@ -144,7 +144,8 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(const GemmArgs p)
     const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
 
     // ---- DMA source addresses: this wave moves pieces q = wave + 4u, piece = 8 rows x 128 B -------------------------
-    const float *src[NLD];
+    // 32-bit element offsets from the (uniform) operand base: every operand is < 2^31 elements (checked on the host)
+    unsigned src[NLD];
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
         const int row = 8 * (wave + 4 * u) + (lane >> 3);
@@ -156,14 +157,14 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(const GemmArgs p)
                 const int b = gm / p.patches, pi = gm - b * p.patches;
                 const int gy = pi / p.gw, gx = pi - gy * p.gw;
                 // per-image channel stride folded in at issue time (depends on k)
-                src[u] = p.A + ((size_t)b * p.lda + (size_t)gy * p.patch * p.img_w + (size_t)gx * p.patch);
+                src[u] = (unsigned)b * (unsigned)p.lda + (unsigned)(gy * p.patch * p.img_w + gx * p.patch);
             } else {
-                src[u] = p.A + (size_t)gm * p.lda + c * 4;
+                src[u] = (unsigned)gm * (unsigned)p.lda + c * 4;
             }
         } else {
             int gn = n0 + row - BM;
             gn = gn < p.N ? gn : p.N - 1;
-            src[u] = p.W + (size_t)gn * p.K + c * 4;
+            src[u] = (unsigned)gn * (unsigned)p.K + c * 4;
         }
     }
 
@@ -172,6 +173,7 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(const GemmArgs p)
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int piece = wave + 4 * u;
+            const float *opnd = 8 * piece < BM ? p.A : p.W;   // wave-uniform
             const float *g;
             if (AMODE == A_PATCH && 8 * piece < BM) {
                 // k = (ch, dy, dx) with dx fastest; this lane's chunk starts at k0 + 4*c, c recovered from src
@@ -179,9 +181,9 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(const GemmArgs p)
                 const int c = (lane & 7) ^ ((row >> 1) & 7);
                 const int k = k0 + 4 * c, pp = p.patch * p.patch;
                 const int ch = k / pp, rem = k - ch * pp, dy = rem / p.patch, dx = rem - dy * p.patch;
-                g = src[u] + ((size_t)ch * p.img_h + dy) * p.img_w + dx;
+                g = opnd + (src[u] + (unsigned)((ch * p.img_h + dy) * p.img_w + dx));
             } else {
-                g = src[u] + k0;
+                g = opnd + (src[u] + (unsigned)k0);
             }
             glds16(g, base + piece * 1024);
         }

@@ -15,10 +15,17 @@ dev = "cuda:0"
 M = 12608
 for name, N, K, epi in (("qkv", 2304, 768, 0), ("o_proj", 768, 768, 2), ("fc1", 3072, 768, 1), ("fc2", 768, 3072, 2)):
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.05; b = torch.randn(N, device=dev)
+    mode = os.environ.get("DATA", "normal")
+    if mode == "zero":
+        x.zero_(); w.zero_()
+    elif mode == "const":
+        x.fill_(1.0); w.fill_(0.5)
+    elif mode == "uniform":
+        x.uniform_(-1, 1); w.uniform_(-1, 1)
     lam = torch.rand(N, device=dev); r = torch.randn(M, N, device=dev); y = torch.empty(M, N, device=dev)
     nblk = ((M + 319) // 320) * ((N + 127) // 128)
     st = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
-    for _ in range(3):
+    for _ in range(int(os.environ.get('REPS', 3))):
         rc = lib.ldit_dbg_linear_stamps(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, epi,
                                         lam.data_ptr(), r.data_ptr(), st.data_ptr(), None)
         assert rc == 0
