@@ -349,10 +349,10 @@ template <int EPI, int AMODE>
 int launch_tiled(const GemmArgs &a, hipStream_t stream)
 {
     // pick the tile that minimises (rounds over 256 CUs) x (tile area) / (tile efficiency): tile quantisation is the
-    // main loss at M = B*197, and small tiles pay more LDS/L2 traffic per FLOP.  LDIT_GEMM_TILE=0|1|2 forces one
+    // main loss at M = B*197, and small tiles pay more LDS/L2 traffic per FLOP.  LDIT_GEMM_TILE=0|1|2|3 forces one
     // (tests use it to cover every instantiation).
     struct Cand { int bm, bn, id; double eff; };
-    const Cand cands[3] = {{320, 128, 0, 1.0}, {128, 128, 1, 0.9}, {64, 64, 2, 0.6}};
+    const Cand cands[4] = {{304, 128, 3, 1.0}, {320, 128, 0, 1.0}, {128, 128, 1, 0.9}, {64, 64, 2, 0.6}};
     double best = -1.0;
     int pick = 2;
     for (const Cand &c : cands) {
@@ -362,8 +362,9 @@ int launch_tiled(const GemmArgs &a, hipStream_t stream)
         if (best < 0 || cost < best) { best = cost; pick = c.id; }
     }
     if (const char *force = getenv("LDIT_GEMM_TILE")) {
-        if (force[0] >= '0' && force[0] <= '2' && force[1] == 0) pick = force[0] - '0';
+        if (force[0] >= '0' && force[0] <= '3' && force[1] == 0) pick = force[0] - '0';
     }
+    if (pick == 3) return launch_gemm_panel(a, EPI, AMODE, stream);   // 304 x 128 panel tiling (gemm_panel_f32.hip)
     switch (pick) {
         case 0: return launch_one<5, 2, EPI, AMODE>(a, stream);
         case 1: return launch_one<2, 2, EPI, AMODE>(a, stream);

@@ -1,0 +1,425 @@
+// fp32 MFMA GEMM, "panel" tiling:  Y[M,N] = epi( A[M,K] . W[N,K]^T ), block tile (32*T32 + 16*HALF) x 128,
+// four waves side by side along N, each owning the full block height x 32 columns.
+//
+// Why a second kernel next to gemm_f32.hip: there every SIMD owns whole 32x32 output tiles and the block height is a
+// multiple of 64.  M = 64 images x 197 tokens = 12608 rows gives 9.23 such tiles per SIMD for N = 768 - rounded up
+// to 10, i.e. 92.3 % of the machine at best, for every GEMM of ViT-B at batch 64.  Here the wave tile is
+// 304 x 32 = nine 32x32 tiles (v_mfma_f32_32x32x2_f32) + one 16-row remainder (two v_mfma_f32_16x16x4_f32 tiles):
+// 42 x N/128 blocks = 252 / 756 / 1008 for N = 768 / 2304 / 3072, i.e. 0.98 / 2.95 / 3.94 rounds of 256 CUs -> 97.2 %.
+// (An all-16x16x4 version of the same tile was measured 10 % slower in the main loop: hipcc rotates the 38 four-register
+// accumulator tuples through VGPRs at the loop edge, 250 v_accvgpr moves per k-tile.  Nine 16-register tuples + two
+// small ones are allocated in place.)
+//
+//   * operands are swapped in the MFMA (A-operand <- W rows, B-operand <- activation rows), so an accumulator register
+//     quad holds 4 CONSECUTIVE output columns of one row: the whole epilogue (bias, erf-GELU, lambda, residual, tap copy,
+//     position add) runs on float4 and stores 16 B per lane - 4x fewer memory instructions than gemm_f32.hip.
+//   * K-contiguous operands -> LDS by LDS-DMA, 128-B rows, 16-B chunk XOR-swizzled with (row>>1)&7 on the source address
+//     and on the read: conflict-free for both read patterns (row = lane&31 / b128 and row = lane&15 / b64).
+//   * 8-deep chunks: a 32-row tile lane (r, h) reads k = 8c+4h..+3 (b128), MFMA step s uses k-pair {s, 4+s};
+//     a 16-row tile lane (r, q) reads k = 8c+4(q&1)+(q>>1) and +2, so its two 16x16x4 steps add k0,k4,k1,k5 | k2,k6,k3,k7:
+//     the same product order as the 32x32x2 steps - results are bit-identical across the two shapes.
+//   * two LDS stages, branch-free k-tile body of four chunks pinned with sched_group_barrier: fragments of chunk c+1 are
+//     read under the MFMAs of chunk c, the DMA pieces of tile kt+1 are dribbled between the MFMAs of chunk 0, the
+//     hand-over barrier sits in front of the last chunk's MFMAs (same pipeline as gemm_f32.hip).
+//   * exact fp32: every output element is one fma chain over k in one fixed order, the same for both MFMA shapes, so a
+//     row's result does not depend on where in a block or batch it sits (tests/test_gpu_forward.py checks bit equality).
+#include <cstdlib>
+
+#include "ldit_common.h"
+
+namespace ldit {
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int ROW_BYTES = BK * 4;
+constexpr int BNP = 128;
+
+__device__ __forceinline__ void glds16p(const float *gsrc, char *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// erf to < 1 ulp, branch-free (see gemm_f32.hip)
+__device__ __forceinline__ float erf_fastp(float a)
+{
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    const float big = copysignf(1.0f - __expf(r), a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    const float small = fmaf(q, a, a);
+    return t > 0.927734375f ? big : small;
+}
+__device__ __forceinline__ float gelup(float v) { return 0.5f * v * (1.0f + erf_fastp(v * 0.70710678118654752440f)); }
+
+// One float4 of the output: row m, columns n..n+3.  VEC: 16-B accesses, no bounds checks (block inside the matrix,
+// ldy % 4 == 0); otherwise element-wise with checks.  `res` = residual values already fetched (EPI_SCALE_RESID).
+template <int EPI, bool VEC, bool DUAL>
+__device__ __forceinline__ void emit4(const GemmArgs &p, int m, int n, f32x4 acc, f32x4 bias, f32x4 lam, f32x4 res)
+{
+    if (!VEC && m >= p.M) return;
+    unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
+    f32x4 pos = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_EMBED) {
+        const int b = m / p.patches, pi = m - b * p.patches;
+        o = ((unsigned)b * p.tokens + 1 + pi) * (unsigned)p.ldy + (unsigned)n;
+        const unsigned po = (unsigned)(1 + pi) * (unsigned)p.N + (unsigned)n;
+        if (VEC) pos = *reinterpret_cast<const f32x4 *>(p.pos + po);
+        else
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pos[r] = (n + r < p.N) ? p.pos[po + r] : 0.0f;
+    }
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = acc[r] + bias[r];
+        if (EPI == EPI_EMBED) t += pos[r];
+        if (EPI == EPI_BIAS_GELU) t = gelup(t);
+        if (EPI == EPI_SCALE_RESID) t = res[r] + lam[r] * t;
+        v[r] = t;
+    }
+    if (VEC) {
+        *reinterpret_cast<f32x4 *>(p.Y + o) = v;
+        if (DUAL) *reinterpret_cast<f32x4 *>(p.Y2 + o) = v;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) {
+                p.Y[o + r] = v[r];
+                if (DUAL) p.Y2[o + r] = v[r];
+            }
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ f32x4 load4(const GemmArgs &p, const float *base, int m, int n, bool row_major_out)
+{
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (VEC) return *reinterpret_cast<const f32x4 *>(base + ((unsigned)m * (unsigned)p.ldy + (unsigned)n));
+    if (m < p.M)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < p.N) v[r] = base[(unsigned)m * (unsigned)p.ldy + (unsigned)(n + r)];
+    (void)row_major_out;
+    return v;
+}
+
+template <bool VEC>
+__device__ __forceinline__ f32x4 vec4(const float *v, int n, int N)
+{
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (!v) return o;
+    if (VEC) return *reinterpret_cast<const f32x4 *>(v + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (n + r < N) o[r] = v[n + r];
+    return o;
+}
+
+// Epilogue of one wave.  32-row tile t, lane (c = lane&31, h = lane>>5): row m0+32t+c, register quad g holds columns
+// nw + 8g + 4h .. +3.  16-row remainder, lane (c = lane&15, q = lane>>4): row m0+32*T32+c, tile it holds nw+16it+4q..+3.
+// The residual quads of the next tile are fetched before the current tile is stored (R may alias Y: fenced so that
+// hipcc neither hoists all loads to the top nor serialises them - see gemm_f32.hip).
+template <int T32, bool HALF, int EPI, bool VEC, bool DUAL>
+__device__ __forceinline__ void store_panel(const GemmArgs &p, const f32x16 (&acc32)[T32], const f32x4 (&acc16)[2], int m0,
+                                            int nw, int lane)
+{
+    const int c32 = lane & 31, h = lane >> 5, c16 = lane & 15, q = lane >> 4;
+    f32x4 bias32[4], lam32[4], res[2][4];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bias32[g] = vec4<VEC>(p.bias, nw + 8 * g + 4 * h, p.N);
+        lam32[g] = EPI == EPI_SCALE_RESID ? vec4<VEC>(p.lam, nw + 8 * g + 4 * h, p.N) : zero;
+        res[0][g] = zero;
+        res[1][g] = zero;
+    }
+    auto fetch = [&](int t, f32x4(&dst)[4]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[g] = load4<VEC>(p, p.R, m0 + 32 * t + c32, nw + 8 * g + 4 * h, true);
+    };
+    if (EPI == EPI_SCALE_RESID && T32 > 0) fetch(0, res[0]);
+#pragma unroll
+    for (int t = 0; t < T32; ++t) {
+        if (EPI == EPI_SCALE_RESID) {
+            if (t + 1 < T32) fetch(t + 1, res[(t + 1) & 1]);
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 a = {acc32[t][4 * g + 0], acc32[t][4 * g + 1], acc32[t][4 * g + 2], acc32[t][4 * g + 3]};
+            emit4<EPI, VEC, DUAL>(p, m0 + 32 * t + c32, nw + 8 * g + 4 * h, a, bias32[g], lam32[g], res[t & 1][g]);
+        }
+        if (EPI == EPI_SCALE_RESID) asm volatile("" ::: "memory");
+    }
+    if (HALF) {
+        const int m = m0 + 32 * T32 + c16;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int n = nw + 16 * it + 4 * q;
+            const f32x4 r = EPI == EPI_SCALE_RESID ? load4<VEC>(p, p.R, m, n, true) : zero;
+            const f32x4 l = EPI == EPI_SCALE_RESID ? vec4<VEC>(p.lam, n, p.N) : zero;
+            emit4<EPI, VEC, DUAL>(p, m, n, acc16[it], vec4<VEC>(p.bias, n, p.N), l, r);
+        }
+    }
+}
+
+template <int T32, bool HALF, int EPI, int AMODE>
+__global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
+{
+    constexpr int BM = 32 * T32 + (HALF ? 16 : 0), BN = BNP, PIECES = (BM + BN) / 8, NLD = (PIECES + 3) / 4;
+    constexpr int STAGE_BYTES = NLD * 4 * 1024;     // pieces past PIECES land in slack rows nobody reads
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c32 = lane & 31, h = lane >> 5, c16 = lane & 15, q = lane >> 4;
+#ifdef LDIT_GEMM_STAMPS
+    unsigned long long st_real0 = __builtin_amdgcn_s_memrealtime(), st_clk0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st_clk1 = 0, st_clk2 = 0;
+#endif
+
+    // ---- block -> tile (XCD-aware, bijective; tiles of one A row-panel are consecutive) ---------------------------
+    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+    const int ntiles = nbm * nbn;
+    int tile;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = ntiles >> 3, rr = ntiles & 7;
+        tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+
+    // ---- DMA sources: this wave moves pieces wave + 4u (8 rows x 128 B each); 32-bit element offsets -----------------
+    unsigned src[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int row = 8 * (wave + 4 * u) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        if (8 * (wave + 4 * u) < BM) {
+            int gm = m0 + row;
+            gm = gm < p.M ? gm : p.M - 1;
+            if (AMODE == A_PATCH) {
+                const int b = gm / p.patches, pi = gm - b * p.patches;
+                const int gy = pi / p.gw, gx = pi - gy * p.gw;
+                src[u] = (unsigned)b * (unsigned)p.lda + (unsigned)(gy * p.patch * p.img_w + gx * p.patch);
+            } else {
+                src[u] = (unsigned)gm * (unsigned)p.lda + c * 4;
+            }
+        } else {
+            int gn = n0 + row - BM;
+            gn = gn < p.N ? gn : p.N - 1;
+            src[u] = (unsigned)gn * (unsigned)p.K + c * 4;
+        }
+    }
+    auto issue = [&](int stage, int k0) {
+        char *base = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int piece = wave + 4 * u;
+            const float *opnd = 8 * piece < BM ? p.A : p.W;
+            const float *g;
+            if (AMODE == A_PATCH && 8 * piece < BM) {
+                const int row = 8 * piece + (lane >> 3);
+                const int c = (lane & 7) ^ ((row >> 1) & 7);
+                const int k = k0 + 4 * c, pp = p.patch * p.patch;
+                const int ch = k / pp, rem = k - ch * pp, dy = rem / p.patch, dx = rem - dy * p.patch;
+                g = opnd + (src[u] + (unsigned)((ch * p.img_h + dy) * p.img_w + dx));
+            } else {
+                g = opnd + (src[u] + (unsigned)k0);
+            }
+            glds16p(g, base + piece * 1024);
+        }
+    };
+
+    f32x16 acc32[T32 > 0 ? T32 : 1];
+    f32x4 acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int t = 0; t < T32; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[t][e] = 0.0f;
+
+    const int nk = p.K / BK;
+    const int sw32 = (c32 >> 1) & 7, sw16 = (c16 >> 1) & 7;
+    const int x32_row = c32 * ROW_BYTES, w32_row = (BM + wave * 32 + c32) * ROW_BYTES;
+    const int x16_row = (32 * T32 + c16) * ROW_BYTES + (q >> 1) * 4, w16_row = (BM + wave * 32 + c16) * ROW_BYTES + (q >> 1) * 4;
+
+    struct Frags {
+        f32x4 x32[T32 > 0 ? T32 : 1];
+        f32x4 w32;
+        f32x2 x16;
+        f32x2 w16[2];
+    };
+    auto load_frags = [&](int stage, int c, Frags &f) {
+        const char *st = smem + stage * STAGE_BYTES;
+        const char *b32 = st + (((c * 2 + h) ^ sw32) * 16);
+#pragma unroll
+        for (int t = 0; t < T32; ++t) f.x32[t] = *reinterpret_cast<const f32x4 *>(b32 + x32_row + t * 32 * ROW_BYTES);
+        f.w32 = *reinterpret_cast<const f32x4 *>(b32 + w32_row);
+        if (HALF) {
+            // lane (r, q), element s <- k = 8c + 4(q&1) + (q>>1) + 2s: the 16x16x4 steps then add the products in the
+            // order k0,k4,k1,k5 | k2,k6,k3,k7 - the order of the 32x32x2 steps above - so a row's result is bit-identical
+            // whichever tile shape it falls into (rows keep their values when the batch composition changes)
+            const char *b16 = st + (((c * 2 + (q & 1)) ^ sw16) * 16);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f.x16[s] = *reinterpret_cast<const float *>(b16 + x16_row + 8 * s);
+                f.w16[0][s] = *reinterpret_cast<const float *>(b16 + w16_row + 8 * s);
+                f.w16[1][s] = *reinterpret_cast<const float *>(b16 + w16_row + 16 * ROW_BYTES + 8 * s);
+            }
+        }
+    };
+    auto mfma_chunk = [&](const Frags &f) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int t = 0; t < T32; ++t)
+                acc32[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w32[s], f.x32[t][s], acc32[t], 0, 0, 0);
+            if (HALF && s < 2) {
+                acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w16[0][s], f.x16[s], acc16[0], 0, 0, 0);
+                acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w16[1][s], f.x16[s], acc16[1], 0, 0, 0);
+            }
+        }
+    };
+
+    constexpr int SG_MFMA = 0x8, SG_VMEM = 0x20, SG_DSR = 0x100;
+    constexpr int NM = 4 * T32 + (HALF ? 4 : 0);          // MFMAs per 8-deep chunk
+    constexpr int NF = T32 + 1 + (HALF ? 3 : 0);          // LDS fragment reads per chunk (the 16-row ones pair up as read2)
+    constexpr int MPD = (NM - NF) / NLD;                  // MFMAs per DMA piece in chunk 0 (0: tile too small)
+    static_assert(NF <= NM, "fewer MFMAs than fragment reads in a chunk");
+
+    Frags f0, f1;
+    issue(0, 0);
+    __syncthreads();
+#ifdef LDIT_GEMM_STAMPS
+    st_clk1 = __builtin_amdgcn_s_memtime();
+#endif
+    load_frags(0, 0, f0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const int knext = (kt + 1 < nk ? kt + 1 : nk - 1) * BK;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- chunk 0: MFMAs of f0 | read chunk 1 -> f1 | DMA tile kt+1 -> stage cur^1 (free since the last hand-over)
+        load_frags(cur, 1, f1);
+        issue(cur ^ 1, knext);
+        mfma_chunk(f0);
+#pragma unroll
+        for (int g = 0; g < NF; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 0);
+        }
+        if (MPD > 0) {
+#pragma unroll
+            for (int g = 0; g < NLD; ++g) {
+                __builtin_amdgcn_sched_group_barrier(SG_MFMA, MPD, 0);
+                __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF - MPD * NLD, 0);
+        } else {
+            __builtin_amdgcn_sched_group_barrier(SG_VMEM, NLD, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- chunk 1: MFMAs of f1 | read chunk 2 -> f0
+        load_frags(cur, 2, f0);
+        mfma_chunk(f1);
+#pragma unroll
+        for (int g = 0; g < NF; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- chunk 2: MFMAs of f0 | read chunk 3 -> f1
+        load_frags(cur, 3, f1);
+        mfma_chunk(f0);
+#pragma unroll
+        for (int g = 0; g < NF; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 2);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 2);
+        }
+        __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- hand-over: own DMA landed (vmcnt 0), own reads of stage cur done (lgkmcnt 0), then all waves
+        __syncthreads();
+        // ---- chunk 3: MFMAs of f1 | read chunk 0 of the next stage -> f0
+        load_frags(cur ^ 1, 0, f0);
+        mfma_chunk(f1);
+#pragma unroll
+        for (int g = 0; g < NF; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 3);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 3);
+        }
+        __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF, 3);
+    }
+
+#ifdef LDIT_GEMM_STAMPS
+    st_clk2 = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    const bool vec = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldy & 3) == 0);   // block-uniform
+    const int nw = n0 + wave * 32;
+    if (vec) {
+        if (p.Y2) store_panel<T32, HALF, EPI, true, true>(p, acc32, acc16, m0, nw, lane);
+        else store_panel<T32, HALF, EPI, true, false>(p, acc32, acc16, m0, nw, lane);
+    } else {
+        if (p.Y2) store_panel<T32, HALF, EPI, false, true>(p, acc32, acc16, m0, nw, lane);
+        else store_panel<T32, HALF, EPI, false, false>(p, acc32, acc16, m0, nw, lane);
+    }
+#ifdef LDIT_GEMM_STAMPS
+    if (p.stamps) {
+        const unsigned long long st_clk3 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st_clk4 = __builtin_amdgcn_s_memtime(), st_real1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long long *o = p.stamps + (size_t)blockIdx.x * 8;
+            o[0] = st_real0; o[1] = st_real1; o[2] = st_clk1 - st_clk0; o[3] = st_clk2 - st_clk1; o[4] = st_clk3 - st_clk2;
+            o[5] = st_clk4 - st_clk3; o[6] = 0; o[7] = tile;
+        }
+    }
+#endif
+}
+
+template <int T32, bool HALF, int EPI, int AMODE>
+int launch_panel(const GemmArgs &a, hipStream_t stream)
+{
+    constexpr int BM = 32 * T32 + (HALF ? 16 : 0), PIECES = (BM + BNP) / 8, NLD = (PIECES + 3) / 4;
+    constexpr int lds = 2 * NLD * 4 * 1024;
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BNP - 1) / BNP);
+    auto kern = gemm_panel_f32<T32, HALF, EPI, AMODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, stream, a);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+}  // namespace
+
+// Panel tiling with a 304 x 128 block.  Arguments already validated by launch_gemm.
+int launch_gemm_panel(const GemmArgs &a, int epi, int amode, hipStream_t stream)
+{
+    if (amode == A_PATCH) return launch_panel<9, true, EPI_EMBED, A_PATCH>(a, stream);
+    switch (epi) {
+        case EPI_BIAS: return launch_panel<9, true, EPI_BIAS, A_ROWMAJOR>(a, stream);
+        case EPI_BIAS_GELU: return launch_panel<9, true, EPI_BIAS_GELU, A_ROWMAJOR>(a, stream);
+        default: return launch_panel<9, true, EPI_SCALE_RESID, A_ROWMAJOR>(a, stream);
+    }
+}
+
+}  // namespace ldit

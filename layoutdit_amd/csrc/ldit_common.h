@@ -10,6 +10,7 @@
 
 namespace ldit {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -48,6 +49,7 @@ struct GemmArgs {
 };
 
 int launch_gemm(const GemmArgs &a, int epi, int amode, hipStream_t stream);
+int launch_gemm_panel(const GemmArgs &a, int epi, int amode, hipStream_t stream);   // 304 x 128 panel tiling (gemm_panel_f32.hip)
 
 // ---- other kernels ---------------------------------------------------------------------------------------------
 int launch_layernorm(const float *X, const float *g, const float *b, float *Y, int64_t rows, int C, float eps,

@@ -23,7 +23,8 @@ for name, N, K, epi in (("qkv", 2304, 768, 0), ("o_proj", 768, 768, 2), ("fc1", 
     elif mode == "uniform":
         x.uniform_(-1, 1); w.uniform_(-1, 1)
     lam = torch.rand(N, device=dev); r = torch.randn(M, N, device=dev); y = torch.empty(M, N, device=dev)
-    nblk = ((M + 319) // 320) * ((N + 127) // 128)
+    bm = 304 if os.environ.get('LDIT_GEMM_TILE', '3') == '3' else 320
+    nblk = ((M + bm - 1) // bm) * ((N + 127) // 128)
     st = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
     for _ in range(int(os.environ.get('REPS', 3))):
         rc = lib.ldit_dbg_linear_stamps(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, epi,

@@ -48,7 +48,7 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["auto", "0", "1", "2"])
+@pytest.mark.parametrize("tile", ["auto", "0", "1", "2", "3"])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_linear_bias(M, N, K, tile):
     if tile != "auto":
@@ -79,7 +79,7 @@ def test_linear_identity_asymmetric():
     np.testing.assert_array_equal(y, w.T)
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "3"])
 def test_linear_gelu_epilogue(tile):
     os.environ["LDIT_GEMM_TILE"] = tile
     M, N, K = 333, 320, 96
@@ -89,7 +89,7 @@ def test_linear_gelu_epilogue(tile):
     np.testing.assert_allclose(y, ref, rtol=1e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "3"])
 def test_linear_scale_residual_inplace_and_tap(tile):
     """h <- h + lam * (x W^T + b), updated IN PLACE (R aliases Y) with a second copy to the tap buffer."""
     os.environ["LDIT_GEMM_TILE"] = tile
