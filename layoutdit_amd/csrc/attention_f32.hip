@@ -2,7 +2,9 @@
 // (TF:models/beit/modeling_beit.py:268-293 eager definition, :323-338 SDPA call; softmax in fp32.)
 //
 // gfx950 design (D = 64):
-//   * one 256-thread workgroup = one (image, head, group of 4 query tiles); wave w owns 32 queries.
+//   * one 512-thread workgroup = one (image, head, group of 8 query tiles); wave w owns 32 queries.  All 7 query tiles
+//     of a 197-token image share ONE staging of the head's K and V, and the two waves per SIMD cover each other's
+//     softmax (VALU) with MFMAs.  (First version: 4-wave groups, K/V staged twice per head, 150 us per layer.)
 //   * K and V of the head are staged in LDS in chunks of KT key tiles (KT = 7 -> all 197 (+pad) keys of a 224x224
 //     image in ONE chunk: 59.5 KiB K (rows padded to 272 B so ds_read_b128 is conflict-free) + 56 KiB V);
 //     longer sequences (N = 1025 at 512x512) stream chunks with the usual online-softmax rescale.
@@ -23,8 +25,8 @@ namespace {
 constexpr int KSTR = 68;   // floats per K row in LDS (64 + 4 pad: 272-B stride -> 16 lanes hit 16 distinct 16-B slots)
 constexpr int VSTR = 64;
 
-template <int KT>
-__global__ void __launch_bounds__(256) attention_f32(const float *__restrict__ Q, const float *__restrict__ K,
+template <int KT, int NW>
+__global__ void __launch_bounds__(NW * 64, NW / 4) attention_f32(const float *__restrict__ Q, const float *__restrict__ K,
                                                      const float *__restrict__ V, float *__restrict__ O, int N, int H,
                                                      int ldq, int ldk, int ldv, int ldo, float scale, int nqg)
 {
@@ -38,7 +40,7 @@ __global__ void __launch_bounds__(256) attention_f32(const float *__restrict__ Q
     const int li = lane & 31, lh = lane >> 5;
     const int bid = blockIdx.x;
     const int qg = bid % nqg, bh = bid / nqg, head = bh % H, b = bh / H;
-    const int qt = qg * 4 + wave;
+    const int qt = qg * NW + wave;
     const bool active = qt * 32 < N;          // wave-uniform
     const size_t tok0 = (size_t)b * N;
 
@@ -65,7 +67,7 @@ __global__ void __launch_bounds__(256) attention_f32(const float *__restrict__ Q
         const int ktiles = (nkeys + 31) >> 5;                    // wave- and block-uniform
         if (c0) __syncthreads();                                 // previous chunk fully consumed
         // ---- stage K, V chunk (zero-fill keys >= N inside the last tile: 0 * garbage must not make NaN) ---------
-        for (int u = tid; u < ktiles * 32 * 16; u += 256) {
+        for (int u = tid; u < ktiles * 32 * 16; u += NW * 64) {
             const int row = u >> 4, c4 = (u & 15) * 4;
             f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
             if (row < nkeys) {
@@ -171,17 +173,17 @@ int launch_attention(const float *Q, const float *K, const float *V, float *O, i
     if (!Q || !K || !V || !O) return fail(LDIT_EINVAL, "attention: null operand");
     if ((ldq | ldk | ldv | ldo) & 3) return fail(LDIT_EINVAL, "attention: row strides must be multiples of 4 floats");
     if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return fail(LDIT_EINVAL, "attention: operands must be 16-byte aligned");
-    constexpr int KT = 7;
+    constexpr int KT = 7, NW = 8;
     constexpr int lds = KT * 32 * (KSTR + VSTR) * 4;
-    const int nqt = (N + 31) / 32, nqg = (nqt + 3) / 4;
-    auto kern = attention_f32<KT>;
+    const int nqt = (N + 31) / 32, nqg = (nqt + NW - 1) / NW;
+    auto kern = attention_f32<KT, NW>;
     static bool attr_set = false;
     if (!attr_set) {
         LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(B * H * nqg)), dim3(256), lds, stream, Q, K, V, O, N, H, ldq, ldk, ldv, ldo,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(B * H * nqg)), dim3(NW * 64), lds, stream, Q, K, V, O, N, H, ldq, ldk, ldv, ldo,
                        scale, nqg);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
