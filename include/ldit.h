@@ -154,6 +154,14 @@ int ldit_embed_f32(const void *x, const void *patch_w, const void *patch_b, cons
 int ldit_tap_to_map_f32(const void *tap, void *out, int64_t B, int64_t Gh, int64_t Gw, int64_t C, float scale,
                         ldit_stream stream);
 
+/* Detector input transform (the step that produces `x`; ref src/layoutdit/modeling/model.py:50-54 configures
+ * torchvision's GeneralizedRCNNTransform with fixed_size = (224, 224), image_mean = image_std = 0.5): for each image
+ * [in_ch, h_i, w_i] in [0,1]:  (img - mean) / std, then bilinear resize (align_corners = False, no antialias) to
+ * out_h x out_w, written as row i of the NCHW batch `out` [B, in_ch, out_h, out_w].  `images`, `heights`, `widths`
+ * are HOST arrays of B entries (device pointers / sizes); at most 65535 images per call. */
+int ldit_preprocess_f32(const void *const *images, const int32_t *heights, const int32_t *widths, int32_t B, int32_t in_ch,
+                        float mean, float std, int32_t out_h, int32_t out_w, void *out, ldit_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

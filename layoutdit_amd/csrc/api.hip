@@ -391,4 +391,15 @@ int ldit_tap_to_map_f32(const void *tap, void *out, int64_t B, int64_t Gh, int64
                              scale, static_cast<hipStream_t>(stream));
 }
 
+int ldit_preprocess_f32(const void *const *images, const int32_t *heights, const int32_t *widths, int32_t B, int32_t in_ch,
+                        float mean, float std, int32_t out_h, int32_t out_w, void *out, ldit_stream stream)
+{
+    if (!images || !heights || !widths || !out) return fail(LDIT_EINVAL, "preprocess: null argument");
+    if (B <= 0 || B > 65535 || in_ch <= 0 || out_h <= 0 || out_w <= 0) return fail(LDIT_EINVAL, "preprocess: bad geometry");
+    if (!(std > 0.0f)) return fail(LDIT_EINVAL, "preprocess: std must be positive");
+    if ((int64_t)B * in_ch * out_h * out_w >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "preprocess: batch exceeds 2^31 elements");
+    return launch_preprocess(reinterpret_cast<const float *const *>(images), heights, widths, B, in_ch, mean, std, out_h, out_w,
+                             static_cast<float *>(out), static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -58,6 +58,8 @@ int launch_attention(const float *Q, const float *K, const float *V, float *O, i
                      int ldk, int ldv, int ldo, float scale, hipStream_t stream);
 int launch_cls_rows(const float *cls, const float *pos, float *out, int B, int tokens, int C, hipStream_t stream);
 int launch_tap_to_map(const float *tap, float *out, int B, int Gh, int Gw, int C, float scale, hipStream_t stream);
+int launch_preprocess(const float *const *images, const int *heights, const int *widths, int B, int in_ch, float mean,
+                      float std, int out_h, int out_w, float *out, hipStream_t stream);
 int launch_pack_qkv_bias(const float *bq, const float *bv, float *dst, int C, hipStream_t stream);
 
 }  // namespace ldit

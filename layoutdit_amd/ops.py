@@ -5,7 +5,8 @@ Every function requires CUDA(=HIP) fp32 contiguous tensors and raises otherwise 
 """
 from __future__ import annotations
 
-from typing import Optional
+import ctypes as C
+from typing import Optional, Sequence
 
 import torch
 
@@ -96,4 +97,23 @@ def tap_to_map(tap: torch.Tensor, gh: int, gw: int, scale: float) -> torch.Tenso
         raise ValueError(f"tap has {T} tokens, grid {gh}x{gw} needs {gh * gw + 1}")
     out = torch.empty((B, Cc, int(gh * scale), int(gw * scale)), device=tap.device, dtype=torch.float32)
     _lib.check(lib.ldit_tap_to_map_f32(_ptr(tap), _ptr(out), B, gh, gw, Cc, float(scale), _stream()))
+    return out
+
+
+def preprocess(images: Sequence[torch.Tensor], size: int = 224, mean: float = 0.5, std: float = 0.5) -> torch.Tensor:
+    """The detector's input transform in one kernel (ref src/layoutdit/modeling/model.py:50-54: fixed_size 224,
+    mean = std = 0.5): list of ``[3, h, w]`` images in [0, 1] -> normalised, bilinearly resized ``[B, 3, size, size]``."""
+    lib = _lib.load()
+    if len(images) == 0:
+        raise ValueError("preprocess: empty image list")
+    imgs = [_req(t, f"images[{i}]") for i, t in enumerate(images)]
+    ch = imgs[0].shape[0]
+    if any(t.dim() != 3 or t.shape[0] != ch for t in imgs):
+        raise ValueError("preprocess: every image must be [C, h, w] with the same C")
+    B = len(imgs)
+    out = torch.empty((B, ch, size, size), device=imgs[0].device, dtype=torch.float32)
+    ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in imgs])
+    hs = (C.c_int32 * B)(*[t.shape[1] for t in imgs])
+    ws = (C.c_int32 * B)(*[t.shape[2] for t in imgs])
+    _lib.check(lib.ldit_preprocess_f32(ptrs, hs, ws, B, ch, mean, std, size, size, _ptr(out), _stream()))
     return out

@@ -80,6 +80,8 @@ def lib(f32acc: bool = False) -> C.CDLL:
         L.oracle_vit_forward.restype = C.c_int
         L.oracle_tap_to_map.argtypes = [fp, i64, i64, i64, i64, C.c_double, fp]
         L.oracle_tap_to_map.restype = None
+        L.oracle_preprocess.argtypes = [fp, i64, i64, i64, C.c_double, C.c_double, i64, i64, fp]
+        L.oracle_preprocess.restype = None
         _LIBS[name] = L
     return _LIBS[name]
 
@@ -134,6 +136,14 @@ def tap_to_map(tap, gh: int, gw: int, scale: float) -> np.ndarray:
     oh, ow = int(np.floor(gh * scale)), int(np.floor(gw * scale))
     out = np.empty((B, Cc, oh, ow), np.float32)
     lib().oracle_tap_to_map(_p(tap), B, gh, gw, Cc, float(scale), _p(out))
+    return out
+
+
+def preprocess(img, size: int = 224, mean: float = 0.5, std: float = 0.5) -> np.ndarray:
+    img = _f32(img)
+    ch, h, w = img.shape
+    out = np.empty((ch, size, size), np.float32)
+    lib().oracle_preprocess(_p(img), ch, h, w, mean, std, size, size, _p(out))
     return out
 
 

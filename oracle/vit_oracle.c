@@ -283,3 +283,34 @@ void oracle_tap_to_map(const float *tap, int64_t B, int64_t Gh, int64_t Gw, int6
         }
     }
 }
+
+/*
+ * Detector input transform (ref src/layoutdit/modeling/model.py:50-54; torchvision GeneralizedRCNNTransform, pinned
+ * 0.19.0, source not in /root/reference -> restated from F.interpolate(size=..., mode="bilinear",
+ * align_corners=False) semantics: src = (dst + 0.5) * in/out - 0.5 clamped at 0).  img [in_ch,h,w] -> out [in_ch,oh,ow].
+ */
+void oracle_preprocess(const float *img, int64_t in_ch, int64_t h, int64_t w, double mean, double std, int64_t oh,
+                       int64_t ow, float *out)
+{
+    const double sch = (double)h / (double)oh, scw = (double)w / (double)ow;
+    for (int64_t ch = 0; ch < in_ch; ++ch)
+        for (int64_t oy = 0; oy < oh; ++oy) {
+            double sy = ((double)oy + 0.5) * sch - 0.5;
+            if (sy < 0) sy = 0;
+            int64_t iy0 = (int64_t)sy;
+            if (iy0 > h - 1) iy0 = h - 1;
+            const int64_t iy1 = iy0 + (iy0 < h - 1 ? 1 : 0);
+            const double ly = sy - (double)iy0, hy = 1.0 - ly;
+            for (int64_t ox = 0; ox < ow; ++ox) {
+                double sx = ((double)ox + 0.5) * scw - 0.5;
+                if (sx < 0) sx = 0;
+                int64_t ix0 = (int64_t)sx;
+                if (ix0 > w - 1) ix0 = w - 1;
+                const int64_t ix1 = ix0 + (ix0 < w - 1 ? 1 : 0);
+                const double lx = sx - (double)ix0, hx = 1.0 - lx;
+                const float *p = img + ch * h * w;
+                const double v = hy * (hx * p[iy0 * w + ix0] + lx * p[iy0 * w + ix1]) + ly * (hx * p[iy1 * w + ix0] + lx * p[iy1 * w + ix1]);
+                out[(ch * oh + oy) * ow + ox] = (float)((v - mean) / std);
+            }
+        }
+}

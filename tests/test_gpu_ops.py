@@ -205,3 +205,32 @@ def test_tap_to_map_vs_oracle(scale):
     tap = _rand(50, 2, 14 * 14 + 1, 192)
     m = ops.tap_to_map(_dev(tap), 14, 14, scale).cpu().numpy()
     assert max_rel(m, oracle.tap_to_map(tap, 14, 14, scale)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ input transform
+def test_preprocess_variable_sizes_vs_oracle_and_torch():
+    """Detector input transform (ref src/layoutdit/modeling/model.py:50-54): normalise with mean = std = 0.5 and resize
+    bilinearly to 224 x 224.  torchvision's source is absent, so parity is against F.interpolate semantics (torch, fp32)
+    and the double-precision restatement in the oracle; the fp32 source-coordinate arithmetic alone moves an output by
+    ~1e-5 on noisy images, hence 1e-4 vs the oracle and 2e-5 vs torch."""
+    import torch.nn.functional as F
+    sizes = [(300, 211), (224, 224), (97, 640), (512, 512), (33, 17)]
+    imgs = [synth.uniform01(50 + i, 1, 3 * h * w).reshape(3, h, w).astype(np.float32) for i, (h, w) in enumerate(sizes)]
+    out = ops.preprocess([_dev(a) for a in imgs]).cpu().numpy()
+    assert out.shape == (len(sizes), 3, 224, 224)
+    for i, a in enumerate(imgs):
+        ref = oracle.preprocess(a)
+        assert np.abs(out[i] - ref).max() < 1e-4, sizes[i]
+        t = F.interpolate(((torch.from_numpy(a) - 0.5) / 0.5)[None], size=(224, 224), mode="bilinear", align_corners=False)[0]
+        assert np.abs(out[i] - t.numpy()).max() < 2e-5, sizes[i]
+
+
+def test_preprocess_many_images_and_bad_arguments():
+    imgs = [_dev(synth.uniform01(80 + i, 1, 3 * 40 * 56).reshape(3, 40, 56).astype(np.float32)) for i in range(70)]
+    out = ops.preprocess(imgs, size=64)              # more than one descriptor batch (48 per launch)
+    one = ops.preprocess(imgs[69:70], size=64)
+    np.testing.assert_array_equal(out[69].cpu().numpy(), one[0].cpu().numpy())
+    with pytest.raises(ValueError):
+        ops.preprocess([])
+    with pytest.raises(ValueError):
+        ops.preprocess([torch.zeros(3, 8, 8)])       # CPU tensor
