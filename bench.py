@@ -44,6 +44,18 @@ def gemm_flops_per_image(cfg, size: int) -> int:
     return 2 * (P * 3 * cfg.patch_size ** 2 * C + L * N * (4 * C * C + 2 * C * Fm))
 
 
+def pmc_traffic(args):
+    """HBM bytes per GEMM launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
+    process).  Only valid for the workload the counters were collected on; otherwise null."""
+    if (args.model, args.size, args.batch) != ("base", 224, 64):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_final_traffic.json")) as f:
+            return round(json.load(f)["gemm_hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def host_cores() -> int:
     """Cores this process may actually use: min(affinity mask, cgroup CPU quota).  The GPU box exposes 256 hardware
     threads but grants a 16-CPU quota per GPU; running 256 threads against that quota thrashes (0.5 img/s)."""
@@ -149,7 +161,8 @@ def main() -> None:
             gemm_flops = gemm_flops_per_image(cfg, args.size) * args.batch * args.steps
             achieved = gemm_flops / (timing["gemm_ms"] * 1e-3) / 1e12
             line["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                                "traffic": pmc_traffic(args),
                                 "kernel": "gemm_f32_mfma (patch-embed, qkv, o_proj, fc1, fc2)",
                                 "launches": n, "avg_launch_ms": round(timing["gemm_ms"] / n, 5),
                                 "flops_per_launch": gemm_flops // n}
