@@ -154,6 +154,17 @@ int ldit_embed_f32(const void *x, const void *patch_w, const void *patch_b, cons
 int ldit_tap_to_map_f32(const void *tap, void *out, int64_t B, int64_t Gh, int64_t Gw, int64_t C, float scale,
                         ldit_stream stream);
 
+/* ---- bf16 path (first build; BASELINE configs 3-5) ------------------------------------------------------------------
+ * Y[M,N] = epilogue(X[M,K] . W[N,K]^T), X and W bf16 (K-contiguous), fp32 accumulation on v_mfma_f32_32x32x16_bf16.
+ * K % 64 == 0, lda % 8 == 0.  bias / lam fp32.  LDIT_EPI_BIAS and LDIT_EPI_BIAS_GELU write bf16 Y;
+ * LDIT_EPI_SCALE_RESID reads the fp32 residual R (may alias Y), writes fp32 Y and the optional fp32 copy Y2. */
+int ldit_linear_bf16(const void *X, int64_t lda, const void *W, const void *bias, void *Y, int64_t ldy, int64_t M,
+                     int64_t N, int64_t K, int32_t epilogue, const void *lam, const void *R, void *Y2,
+                     ldit_stream stream);
+
+/* dst[i] = bf16(src[i]) (round to nearest even), n elements. */
+int ldit_cast_f32_bf16(const void *src, void *dst, int64_t n, ldit_stream stream);
+
 /* Detector input transform (the step that produces `x`; ref src/layoutdit/modeling/model.py:50-54 configures
  * torchvision's GeneralizedRCNNTransform with fixed_size = (224, 224), image_mean = image_std = 0.5): for each image
  * [in_ch, h_i, w_i] in [0,1]:  (img - mean) / std, then bilinear resize (align_corners = False, no antialias) to

@@ -391,6 +391,26 @@ int ldit_tap_to_map_f32(const void *tap, void *out, int64_t B, int64_t Gh, int64
                              scale, static_cast<hipStream_t>(stream));
 }
 
+int ldit_linear_bf16(const void *X, int64_t lda, const void *W, const void *bias, void *Y, int64_t ldy, int64_t M,
+                     int64_t N, int64_t K, int32_t epilogue, const void *lam, const void *R, void *Y2, ldit_stream stream)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return fail(LDIT_EINVAL, "linear_bf16: empty problem");
+    if (M * (ldy > lda ? ldy : lda) >= (1ll << 31) || N * K >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "linear_bf16: operand exceeds 2^31 elements");
+    if (ldy < N || lda < K) return fail(LDIT_EINVAL, "linear_bf16: bad leading dimension");
+    if (!Y || !aligned16(Y) || (Y2 && !aligned16(Y2))) return fail(LDIT_EINVAL, "linear_bf16: output null or misaligned");
+    if (epilogue < LDIT_EPI_BIAS || epilogue > LDIT_EPI_SCALE_RESID) return fail(LDIT_EINVAL, "linear_bf16: unknown epilogue %d", epilogue);
+    return launch_gemm_bf16(X, (int)lda, W, static_cast<const float *>(bias), Y, (int)ldy, (int)M, (int)N, (int)K, epilogue,
+                            static_cast<const float *>(lam), static_cast<const float *>(R), static_cast<float *>(Y2),
+                            static_cast<hipStream_t>(stream));
+}
+
+int ldit_cast_f32_bf16(const void *src, void *dst, int64_t n, ldit_stream stream)
+{
+    if (n < 0 || (n && (!src || !dst))) return fail(LDIT_EINVAL, "cast: null operand");
+    if (!aligned16(src) || (reinterpret_cast<uintptr_t>(dst) & 7u)) return fail(LDIT_EINVAL, "cast: misaligned operand");
+    return launch_cvt_bf16(static_cast<const float *>(src), dst, (size_t)n, static_cast<hipStream_t>(stream));
+}
+
 int ldit_preprocess_f32(const void *const *images, const int32_t *heights, const int32_t *widths, int32_t B, int32_t in_ch,
                         float mean, float std, int32_t out_h, int32_t out_w, void *out, ldit_stream stream)
 {

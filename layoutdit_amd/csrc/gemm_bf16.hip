@@ -1,0 +1,326 @@
+// bf16 MFMA GEMM with fused epilogues:  Y[M,N] = epi( A[M,K] . W[N,K]^T ),  A, W bf16 (K-contiguous), fp32 accumulate.
+// First bf16 build of the path (BASELINE configs 3-5 are bf16 / fp8; config 4 = ViT-L/16 512x512 bs=16 forward).
+//
+// Same skeleton as the fp32 kernels: K-contiguous operands -> LDS by LDS-DMA (global_load_lds_dwordx4), 128-B LDS rows
+// (64 bf16), 16-B chunk XOR-swizzled with (row>>1)&7 on the source address and on the read, two stages, fragments of
+// k-step s+1 read while step s multiplies.  v_mfma_f32_32x32x16_bf16: lane (r, h) supplies 8 consecutive k (16 B =
+// ONE ds_read_b128) per 32-row tile and 16-deep step, so a 64-deep k-tile is four steps of TM*TN MFMAs.
+// Operands are swapped in the MFMA (A-operand <- W rows, B-operand <- activation rows): an accumulator register quad
+// holds 4 consecutive output columns of one row -> 16-B fp32 / 8-B bf16 stores.
+// Block = 2 x 2 waves, wave tile TM x TN 32x32 tiles; 256x256 (TM = TN = 4) keeps the DMA issue (one 1-KiB piece per
+// ~60 cycles per wave) under the MFMA time of a k-tile; smaller tiles are DMA-issue bound.
+//
+// Epilogues: bias -> bf16 ; bias + erf-GELU -> bf16 ; R + lam (.) (acc + bias) -> fp32 (in place on the fp32 residual
+// stream, optional fp32 tap copy).
+#include <cstdlib>
+
+#include "ldit_common.h"
+
+namespace ldit {
+
+namespace {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BKB = 64;            // bf16 per k-tile: one 128-B LDS row
+constexpr int ROWB = 128;
+
+__device__ __forceinline__ void glds16h(const void *gsrc, char *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float erf_fasth(float a)
+{
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    const float big = copysignf(1.0f - __expf(r), a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    const float small = fmaf(q, a, a);
+    return t > 0.927734375f ? big : small;
+}
+__device__ __forceinline__ float geluh(float v) { return 0.5f * v * (1.0f + erf_fasth(v * 0.70710678118654752440f)); }
+
+struct GemmArgsH {
+    const bf16_t *A;     // [M, K] bf16
+    const bf16_t *W;     // [N, K] bf16
+    void *Y;             // [M, N] bf16 (BIAS, BIAS_GELU) or fp32 (SCALE_RESID)
+    float *Y2;           // optional fp32 tap copy (SCALE_RESID)
+    const float *bias;   // [N] fp32 or null
+    const float *lam;    // [N] fp32
+    const float *R;      // [M, N] fp32, may alias Y
+    int M, N, K, lda, ldy;
+};
+
+template <int TM, int TN, int EPI, bool CHECK>
+__device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane)
+{
+    const int c32 = lane & 31, h = lane >> 5;
+    const bool dual = p.Y2 != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        f32x4 bias[4], lam[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = nw + j * 32 + 8 * g + 4 * h + e;
+                const bool ok = !CHECK || n < p.N;
+                bias[g][e] = (ok && p.bias) ? p.bias[n] : 0.0f;
+                lam[g][e] = (EPI == EPI_SCALE_RESID && ok) ? p.lam[n] : 0.0f;
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = mw + i * 32 + c32;
+            if (CHECK && m >= p.M) continue;
+            f32x4 res[4];
+            if (EPI == EPI_SCALE_RESID) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nw + j * 32 + 8 * g + 4 * h;
+                    const unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
+                    if (!CHECK) res[g] = *reinterpret_cast<const f32x4 *>(p.R + o);
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) res[g][e] = (n + e < p.N) ? p.R[o + e] : 0.0f;
+                }
+                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nw + j * 32 + 8 * g + 4 * h;
+                const unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][j][4 * g + e] + bias[g][e];
+                    if (EPI == EPI_BIAS_GELU) t = geluh(t);
+                    if (EPI == EPI_SCALE_RESID) t = res[g][e] + lam[g][e] * t;
+                    v[e] = t;
+                }
+                if (EPI == EPI_SCALE_RESID) {
+                    float *y = static_cast<float *>(p.Y);
+                    if (!CHECK) {
+                        *reinterpret_cast<f32x4 *>(y + o) = v;
+                        if (dual) *reinterpret_cast<f32x4 *>(p.Y2 + o) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) { y[o + e] = v[e]; if (dual) p.Y2[o + e] = v[e]; }
+                    }
+                } else {
+                    bf16_t *y = static_cast<bf16_t *>(p.Y);
+                    if (!CHECK) {
+                        const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        *reinterpret_cast<bf16x4 *>(y + o) = pk;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) y[o + e] = (bf16_t)v[e];
+                    }
+                }
+            }
+            if (EPI == EPI_SCALE_RESID) asm volatile("" ::: "memory");
+        }
+    }
+}
+
+template <int TM, int TN, int EPI>
+__global__ void __launch_bounds__(256) gemm_bf16_mfma(const GemmArgsH p)
+{
+    constexpr int BM = 64 * TM, BN = 64 * TN, ROWS = BM + BN, NLD = ROWS / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int c32 = lane & 31, h = lane >> 5;
+
+    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+    const int ntiles = nbm * nbn;
+    int tile;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = ntiles >> 3, rr = ntiles & 7;
+        tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+
+    unsigned src[NLD];   // element (bf16) offsets
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int row = 8 * (wave + 4 * u) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        if (8 * (wave + 4 * u) < BM) {
+            int gm = m0 + row;
+            gm = gm < p.M ? gm : p.M - 1;
+            src[u] = (unsigned)gm * (unsigned)p.lda + c * 8;
+        } else {
+            int gn = n0 + row - BM;
+            gn = gn < p.N ? gn : p.N - 1;
+            src[u] = (unsigned)gn * (unsigned)p.K + c * 8;
+        }
+    }
+    auto issue = [&](int stage, int k0) {
+        char *base = smem + stage * (ROWS * ROWB);
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int piece = wave + 4 * u;
+            const bf16_t *opnd = 8 * piece < BM ? p.A : p.W;
+            glds16h(opnd + (src[u] + (unsigned)k0), base + piece * 1024);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int sw = (c32 >> 1) & 7;
+    const int nk = p.K / BKB;
+    const int a_row = (wm * TM * 32 + c32) * ROWB, b_row = (BM + wn * TN * 32 + c32) * ROWB;
+    auto load_frags = [&](int stage, int s, bf16x8(&xa)[TM], bf16x8(&wb)[TN]) {
+        const char *base = smem + stage * (ROWS * ROWB) + ((s * 2 + h) ^ sw) * 16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const bf16x8 *>(base + a_row + i * 32 * ROWB);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wb[j] = *reinterpret_cast<const bf16x8 *>(base + b_row + j * 32 * ROWB);
+    };
+    auto mfma_step = [&](const bf16x8(&xa)[TM], const bf16x8(&wb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+    };
+
+    // same pipeline as the fp32 kernels: step s+1 fragments are read under step s MFMAs, the DMA of tile kt+1 is issued
+    // in step 0, the hand-over barrier sits in front of the last step's MFMAs.
+    bf16x8 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
+    issue(0, 0);
+    __syncthreads();
+    load_frags(0, 0, xa0, wb0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const int knext = (kt + 1 < nk ? kt + 1 : nk - 1) * BKB;
+        load_frags(cur, 1, xa1, wb1);
+        issue(cur ^ 1, knext);
+        mfma_step(xa0, wb0);
+        load_frags(cur, 2, xa0, wb0);
+        mfma_step(xa1, wb1);
+        load_frags(cur, 3, xa1, wb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(xa0, wb0);
+        __syncthreads();
+        load_frags(cur ^ 1, 0, xa0, wb0);
+        mfma_step(xa1, wb1);
+    }
+
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
+    const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
+    if (interior) store_h<TM, TN, EPI, false>(p, acc, mw, nw, lane);
+    else store_h<TM, TN, EPI, true>(p, acc, mw, nw, lane);
+}
+
+template <int TM, int TN, int EPI>
+int launch_h(const GemmArgsH &a, hipStream_t stream)
+{
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int lds = 2 * (BM + BN) * ROWB;
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    auto kern = gemm_bf16_mfma<TM, TN, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, stream, a);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+template <int EPI>
+int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
+{
+    struct Cand { int bm, bn, id; double eff; };
+    const Cand cands[3] = {{256, 256, 0, 1.0}, {256, 128, 1, 0.8}, {128, 128, 2, 0.55}};
+    double best = -1.0;
+    int pick = 2;
+    for (const Cand &c : cands) {
+        const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
+        const long rounds = (tiles + 255) / 256;
+        const double cost = (double)rounds * c.bm * c.bn / c.eff;
+        if (best < 0 || cost < best) { best = cost; pick = c.id; }
+    }
+    if (const char *force = getenv("LDIT_GEMM_BF16_TILE")) {
+        if (force[0] >= '0' && force[0] <= '2' && force[1] == 0) pick = force[0] - '0';
+    }
+    switch (pick) {
+        case 0: return launch_h<4, 4, EPI>(a, stream);
+        case 1: return launch_h<4, 2, EPI>(a, stream);
+        default: return launch_h<2, 2, EPI>(a, stream);
+    }
+}
+
+// fp32 -> bf16 (round to nearest even), n elements, 4 per thread
+__global__ void __launch_bounds__(256) cvt_f32_bf16(const float *__restrict__ src, bf16_t *__restrict__ dst, size_t n)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + i);
+        const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4 *>(dst + i) = o;
+    } else {
+        for (size_t k = i; k < n; ++k) dst[k] = (bf16_t)src[k];
+    }
+}
+
+}  // namespace
+
+int launch_gemm_bf16(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
+                     const float *lam, const float *R, float *Y2, hipStream_t stream)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return fail(LDIT_EINVAL, "gemm_bf16: empty problem");
+    if (K % BKB) return fail(LDIT_EUNSUPPORTED, "gemm_bf16: K=%d must be a multiple of %d", K, BKB);
+    if (!A || !W || !Y) return fail(LDIT_EINVAL, "gemm_bf16: null operand");
+    if (!aligned16(A) || !aligned16(W) || (lda & 7)) return fail(LDIT_EINVAL, "gemm_bf16: operands must be 16-byte aligned");
+    GemmArgsH a{};
+    a.A = static_cast<const bf16_t *>(A); a.W = static_cast<const bf16_t *>(W); a.Y = Y; a.Y2 = Y2; a.bias = bias; a.lam = lam;
+    a.R = R; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldy = ldy;
+    switch (epi) {
+        case EPI_BIAS: return launch_h_tiled<EPI_BIAS>(a, stream);
+        case EPI_BIAS_GELU: return launch_h_tiled<EPI_BIAS_GELU>(a, stream);
+        case EPI_SCALE_RESID:
+            if (!lam || !R) return fail(LDIT_EINVAL, "gemm_bf16: scale+residual epilogue needs lam and R");
+            return launch_h_tiled<EPI_SCALE_RESID>(a, stream);
+        default: return fail(LDIT_EINVAL, "gemm_bf16: unknown epilogue %d", epi);
+    }
+}
+
+int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream)
+{
+    if (n == 0) return LDIT_OK;
+    hipLaunchKernelGGL(cvt_f32_bf16, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream, src,
+                       static_cast<bf16_t *>(dst), n);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+}  // namespace ldit

@@ -60,6 +60,9 @@ int launch_cls_rows(const float *cls, const float *pos, float *out, int B, int t
 int launch_tap_to_map(const float *tap, float *out, int B, int Gh, int Gw, int C, float scale, hipStream_t stream);
 int launch_preprocess(const float *const *images, const int *heights, const int *widths, int B, int in_ch, float mean,
                       float std, int out_h, int out_w, float *out, hipStream_t stream);
+int launch_gemm_bf16(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
+                     const float *lam, const float *R, float *Y2, hipStream_t stream);
+int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream);
 int launch_pack_qkv_bias(const float *bq, const float *bv, float *dst, int C, hipStream_t stream);
 
 }  // namespace ldit

@@ -117,3 +117,34 @@ def preprocess(images: Sequence[torch.Tensor], size: int = 224, mean: float = 0.
     ws = (C.c_int32 * B)(*[t.shape[2] for t in imgs])
     _lib.check(lib.ldit_preprocess_f32(ptrs, hs, ws, B, ch, mean, std, size, size, _ptr(out), _stream()))
     return out
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> bf16 (round to nearest even) on the library's conversion kernel."""
+    lib = _lib.load()
+    x = _req(x, "x")
+    out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    _lib.check(lib.ldit_cast_f32_bf16(_ptr(x), _ptr(out), x.numel(), _stream()))
+    return out
+
+
+def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = _lib.EPI_BIAS,
+                lam: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 MFMA GEMM: ``x`` [M, K] bf16, ``weight`` [N, K] bf16, fp32 accumulation; bf16 result for the bias / GELU
+    epilogues, fp32 (in place on ``residual`` if ``out is residual``) for the scale+residual epilogue."""
+    lib = _lib.load()
+    for t, n in ((x, "x"), (weight, "weight")):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
+            raise ValueError(f"{n}: expected a contiguous bfloat16 GPU tensor")
+    M, K = x.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=x.device,
+                          dtype=torch.float32 if epilogue == _lib.EPI_SCALE_RESID else torch.bfloat16)
+    for t, n in ((bias, "bias"), (lam, "lam"), (residual, "residual"), (out2, "out2")):
+        if t is not None:
+            _req(t, n)
+    _lib.check(lib.ldit_linear_bf16(_ptr(x), K, _ptr(weight), _ptr(bias), _ptr(out), N, M, N, K, epilogue, _ptr(lam),
+                                    _ptr(residual), _ptr(out2), _stream()))
+    return out
