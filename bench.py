@@ -34,6 +34,7 @@ from layoutdit_amd import config as cfgs, dp, synth           # noqa: E402
 from layoutdit_amd.modeling import DiTEncoder                 # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3    # gfx950 dense fp32 matrix peak (spec; 155 measured), MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense MFMA peaks (bf16: ~2.5 PF dense, never the 2:1-sparse figure)
 PER_GPU_BATCH = 64
 
 
@@ -47,7 +48,7 @@ def gemm_flops_per_image(cfg, size: int) -> int:
 def pmc_traffic(args):
     """HBM bytes per GEMM launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
     process).  Only valid for the workload the counters were collected on; otherwise null."""
-    if (args.model, args.size, args.batch) != ("base", 224, 64):
+    if (args.model, args.size, args.batch, args.dtype) != ("base", 224, 64, "f32"):
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_final_traffic.json")) as f:
@@ -95,6 +96,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="base", choices=sorted(cfgs.GEOMETRIES))
     ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = BASELINE configs[1] (headline); bf16 with --model large --size 512 --batch 16 = configs[3]")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU")
     ap.add_argument("--cpu-sample", type=int, default=64, help="images timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-roofline-pass", action="store_true")
@@ -110,7 +113,7 @@ def main() -> None:
 
     cfg = cfgs.GEOMETRIES[args.model]()
     weights = synth.synth_weights(cfg, seed=0)
-    model = DiTEncoder(cfg).load_numpy(weights).to(dev).eval()
+    model = DiTEncoder(cfg, compute_dtype=args.dtype).load_numpy(weights).to(dev).eval()
     lo, hi = dp.shard_range(args.batch * r.world, r.rank, r.world)       # weak scaling: args.batch images per rank
     x_np = synth.synth_images(hi - lo, args.size, args.size, seed=1234, first_index=lo)
     x = torch.from_numpy(x_np).to(dev)                                    # resident in HBM before the timed region
@@ -142,32 +145,37 @@ def main() -> None:
         images = args.batch * r.world * args.steps
         ms_per_step = 1e3 * elapsed / args.steps
         line = {
-            "metric": "images/sec ViT-B/16 224px bs=64 fwd" if (args.model, args.size, args.batch) == ("base", 224, 64)
-            else f"images/sec ViT-{args.model}/16 {args.size}px bs={args.batch} fwd",
+            "metric": "images/sec ViT-B/16 224px bs=64 fwd"
+            if (args.model, args.size, args.batch, args.dtype) == ("base", 224, 64, "f32")
+            else f"images/sec ViT-{args.model}/16 {args.size}px bs={args.batch} {args.dtype} fwd",
             "value": round(images / elapsed, 2), "unit": "images/sec", "n_gpus": r.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ViT-{args.model}/16 {args.size}x{args.size} bs={args.batch} fp32 forward, taps "
-                                   f"{cfg.taps} (BASELINE.json configs[1])",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"ViT-{args.model}/16 {args.size}x{args.size} bs={args.batch} {args.dtype} forward, taps "
+                                   f"{cfg.taps}" + (" (BASELINE.json configs[1])"
+                                                    if (args.model, args.size, args.batch, args.dtype) == ("base", 224, 64, "f32")
+                                                    else ""),
                        "images_per_gpu": args.batch, "global_batch": args.batch * r.world,
                        "parallelism": f"dp{r.world}: batch-sharded replicas, no data-path collective",
                        "weights": "synthetic seed 0", "images": "synthetic doc-like pages, seed 1234"},
         }
         flops_img = cfg.flops_per_image(args.size, args.size)
         line["model_tflops"] = round(flops_img * args.batch * r.world / (ms_per_step * 1e-3) / 1e12, 2)
-        line["model_mfma_roofline_frac"] = round(line["model_tflops"] / (PEAK_F32_MFMA_TFLOPS * r.world), 4)
+        peak = PEAK_TFLOPS[args.dtype]
+        line["model_mfma_roofline_frac"] = round(line["model_tflops"] / (peak * r.world), 4)
         if timing:
             n = int(timing["gemm_launches"])
             gemm_flops = gemm_flops_per_image(cfg, args.size) * args.batch * args.steps
             achieved = gemm_flops / (timing["gemm_ms"] * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+            line["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                                 "traffic": pmc_traffic(args),
-                                "kernel": "gemm_f32_mfma (patch-embed, qkv, o_proj, fc1, fc2)",
+                                "kernel": "fp32 MFMA GEMM family (patch-embed, qkv, o_proj, fc1, fc2)" if args.dtype == "f32"
+                                else "bf16 MFMA GEMM family (qkv, o_proj, fc1, fc2; patch-embed stays fp32)",
                                 "launches": n, "avg_launch_ms": round(timing["gemm_ms"] / n, 5),
                                 "flops_per_launch": gemm_flops // n}
             line["kernel_ms_per_step"] = {k[:-3]: round(v / args.steps, 4) for k, v in timing.items() if k.endswith("_ms")}
-        if r.world == 1 and args.cpu_sample > 0 and args.model == "base":
+        if r.world == 1 and args.cpu_sample > 0 and args.model == "base" and args.dtype == "f32":
             line["cpu_baseline"] = cpu_baseline(cfg, weights, x_np, min(args.cpu_sample, args.batch))
         print(json.dumps(line), flush=True)
     dp.finalize(r)

@@ -37,7 +37,10 @@ enum ldit_status {
     LDIT_EUNSUPPORTED = -4  /* geometry outside what the kernels handle (see each function) */
 };
 
-enum ldit_dtype { LDIT_F32 = 0 };
+enum ldit_dtype {
+    LDIT_F32 = 0,  /* everything fp32 (exact-fp32 MFMA) */
+    LDIT_BF16 = 1  /* GEMM / attention operands bf16, fp32 accumulation, residual stream / LayerNorm / softmax fp32; taps fp32 */
+};
 
 /* epilogues of ldit_linear_f32 (what is fused behind the matmul) */
 enum ldit_epilogue {
@@ -161,6 +164,11 @@ int ldit_tap_to_map_f32(const void *tap, void *out, int64_t B, int64_t Gh, int64
 int ldit_linear_bf16(const void *X, int64_t lda, const void *W, const void *bias, void *Y, int64_t ldy, int64_t M,
                      int64_t N, int64_t K, int32_t epilogue, const void *lam, const void *R, void *Y2,
                      ldit_stream stream);
+
+/* softmax(Q K^T * scale) V per head; Q, K, V bf16 [B, N, H*D] token-major (row strides in bf16 elements), O bf16;
+ * fp32 softmax and accumulation.  D == 64. */
+int ldit_attention_bf16(const void *Q, const void *K, const void *V, void *O, int64_t B, int64_t N, int64_t H, int64_t D,
+                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, ldit_stream stream);
 
 /* dst[i] = bf16(src[i]) (round to nearest even), n elements. */
 int ldit_cast_f32_bf16(const void *src, void *dst, int64_t n, ldit_stream stream);

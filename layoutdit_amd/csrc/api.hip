@@ -33,13 +33,15 @@ struct Geo {
 int geometry(const ldit_cfg *cfg, Geo &g)
 {
     if (!cfg) return fail(LDIT_EINVAL, "cfg is null");
-    if (cfg->dtype != LDIT_F32) return fail(LDIT_EUNSUPPORTED, "dtype %d: only fp32 is implemented", cfg->dtype);
+    if (cfg->dtype != LDIT_F32 && cfg->dtype != LDIT_BF16)
+        return fail(LDIT_EUNSUPPORTED, "dtype %d: only fp32 (0) and bf16 (1) are implemented", cfg->dtype);
     g.C = cfg->hidden; g.L = cfg->layers; g.H = cfg->heads; g.F = cfg->mlp; g.p = cfg->patch; g.in_ch = cfg->in_ch;
     if (g.C <= 0 || g.L < 0 || g.H <= 0 || g.F <= 0 || g.p <= 0 || g.in_ch <= 0) return fail(LDIT_EINVAL, "cfg: non-positive dimension");
     if (g.C % g.H) return fail(LDIT_EINVAL, "cfg: hidden %d not divisible by heads %d", g.C, g.H);
     g.D = g.C / g.H;
     if (g.D != 64) return fail(LDIT_EUNSUPPORTED, "cfg: head_dim %d, only 64 is implemented", g.D);
     if (g.C % 32 || g.F % 32) return fail(LDIT_EUNSUPPORTED, "cfg: hidden and mlp must be multiples of 32");
+    if (cfg->dtype == LDIT_BF16 && (g.C % 64 || g.F % 64)) return fail(LDIT_EUNSUPPORTED, "cfg: bf16 needs hidden and mlp multiples of 64");
     if (cfg->img_h <= 0 || cfg->img_w <= 0 || cfg->img_h % g.p || cfg->img_w % g.p)
         return fail(LDIT_EINVAL, "cfg: image %dx%d is not a multiple of patch %d", cfg->img_h, cfg->img_w, g.p);
     g.gh = cfg->img_h / g.p; g.gw = cfg->img_w / g.p; g.P = g.gh * g.gw; g.T = g.P + 1;
@@ -51,31 +53,33 @@ int geometry(const ldit_cfg *cfg, Geo &g)
     return LDIT_OK;
 }
 
-// Offsets (in floats) into the packed parameter block; every offset is a multiple of 4 floats.
+// Byte offsets into the packed parameter block; every offset is a multiple of 16 bytes.  In the bf16 build the four
+// big matrices of a layer (fused q|k|v, o_proj, fc1, fc2) are stored as bf16; everything else stays fp32.
 struct PackedLayer { size_t ln1_w, ln1_b, wqkv, bqkv, wo, bo, lam1, ln2_w, ln2_b, w1, b1, w2, b2, lam2; };
 struct PackedMap {
     size_t patch_w, patch_b, cls, pos, total;
     std::vector<PackedLayer> layer;
 };
 
-PackedMap packed_map(const Geo &g)
+PackedMap packed_map(const Geo &g, int dtype)
 {
     PackedMap m;
     size_t o = 0;
-    auto take = [&](size_t n) { size_t at = o; o += up(n, 4); return at; };
-    m.patch_w = take((size_t)g.C * g.Kp);
-    m.patch_b = take(g.C);
-    m.cls = take(g.C);
-    m.pos = take((size_t)g.T * g.C);
+    const size_t mat = dtype == LDIT_BF16 ? 2 : 4;
+    auto take = [&](size_t n, size_t elt) { size_t at = o; o += up(n * elt, 16); return at; };
+    m.patch_w = take((size_t)g.C * g.Kp, 4);
+    m.patch_b = take(g.C, 4);
+    m.cls = take(g.C, 4);
+    m.pos = take((size_t)g.T * g.C, 4);
     m.layer.resize(g.L);
     for (int l = 0; l < g.L; ++l) {
         PackedLayer &pl = m.layer[l];
-        pl.ln1_w = take(g.C); pl.ln1_b = take(g.C);
-        pl.wqkv = take((size_t)3 * g.C * g.C); pl.bqkv = take((size_t)3 * g.C);
-        pl.wo = take((size_t)g.C * g.C); pl.bo = take(g.C); pl.lam1 = take(g.C);
-        pl.ln2_w = take(g.C); pl.ln2_b = take(g.C);
-        pl.w1 = take((size_t)g.F * g.C); pl.b1 = take(g.F);
-        pl.w2 = take((size_t)g.C * g.F); pl.b2 = take(g.C); pl.lam2 = take(g.C);
+        pl.ln1_w = take(g.C, 4); pl.ln1_b = take(g.C, 4);
+        pl.wqkv = take((size_t)3 * g.C * g.C, mat); pl.bqkv = take((size_t)3 * g.C, 4);
+        pl.wo = take((size_t)g.C * g.C, mat); pl.bo = take(g.C, 4); pl.lam1 = take(g.C, 4);
+        pl.ln2_w = take(g.C, 4); pl.ln2_b = take(g.C, 4);
+        pl.w1 = take((size_t)g.F * g.C, mat); pl.b1 = take(g.F, 4);
+        pl.w2 = take((size_t)g.C * g.F, mat); pl.b2 = take(g.C, 4); pl.lam2 = take(g.C, 4);
     }
     m.total = o;
     return m;
@@ -83,16 +87,17 @@ PackedMap packed_map(const Geo &g)
 
 struct Workspace { size_t h, y, big, total; };   // byte offsets
 
-Workspace workspace_map(const Geo &g, int batch)
+Workspace workspace_map(const Geo &g, int batch, int dtype)
 {
     const size_t M = (size_t)batch * g.T;
     const size_t wide = (size_t)(3 * g.C > g.F ? 3 * g.C : g.F);
+    const size_t act = dtype == LDIT_BF16 ? 2 : 4;
     Workspace w;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += up(bytes, 256); return at; };
-    w.h = take(M * g.C * 4);       // residual stream
-    w.y = take(M * g.C * 4);       // LayerNorm output, then attention output
-    w.big = take(M * wide * 4);    // fused q|k|v, later the MLP hidden (never live together)
+    w.h = take(M * g.C * 4);       // residual stream (always fp32)
+    w.y = take(M * g.C * act);     // LayerNorm output, then attention output
+    w.big = take(M * wide * act);  // fused q|k|v, later the MLP hidden (never live together)
     w.total = o;
     return w;
 }
@@ -185,10 +190,11 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
         if (!tap_out[i] || !aligned16(tap_out[i])) return fail(LDIT_EINVAL, "tap_out[%d] is null or misaligned", i);
     if ((int64_t)batch * g.T * (int64_t)(g.F > 3 * g.C ? g.F : 3 * g.C) >= (1ll << 31))
         return fail(LDIT_EUNSUPPORTED, "batch %d: activation index space exceeds 2^31 elements, split the batch", batch);
-    const Workspace wm = workspace_map(g, batch);
+    const Workspace wm = workspace_map(g, batch, cfg->dtype);
     if (ws_bytes < wm.total) return fail(LDIT_EWORKSPACE, "workspace %zu bytes < required %zu", ws_bytes, wm.total);
-    const PackedMap pm = packed_map(g);
-    const float *P = static_cast<const float *>(packed);
+    const PackedMap pm = packed_map(g, cfg->dtype);
+    const char *P = static_cast<const char *>(packed);
+    auto F32 = [&](size_t off) { return reinterpret_cast<const float *>(P + off); };
     char *ws = static_cast<char *>(workspace);
     float *h = reinterpret_cast<float *>(ws + wm.h);
     float *y = reinterpret_cast<float *>(ws + wm.y);
@@ -209,8 +215,8 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
         return LDIT_OK;
     };
 
-    // embeddings (TF:153-176)
-    LDIT_TRY(embed(g, static_cast<const float *>(x), P + pm.patch_w, P + pm.patch_b, P + pm.cls, P + pm.pos, h, batch,
+    // embeddings (TF:153-176): always the fp32 kernel (0.7 % of the FLOPs; the image batch is fp32)
+    LDIT_TRY(embed(g, static_cast<const float *>(x), F32(pm.patch_w), F32(pm.patch_b), F32(pm.cls), F32(pm.pos), h, batch,
                    cfg->img_h, cfg->img_w, stream, probe));
     if (float *t0 = tap_for(0)) {
         LDIT_HIP_CHECK(hipMemcpyAsync(t0, h, act_bytes, hipMemcpyDeviceToDevice, stream));
@@ -218,24 +224,44 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
     }
 
     const float scale = 1.0f / sqrtf((float)g.D);
+    const bool bf16 = cfg->dtype == LDIT_BF16;
     for (int l = 0; l < g.L; ++l) {
         const PackedLayer &pl = pm.layer[l];
-        // y = LN1(h)                                                               TF:426
-        LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm(h, P + pl.ln1_w, P + pl.ln1_b, y, M, C, cfg->ln_eps, stream));
-        // big[:, 0:3C] = y . [Wq;Wk;Wv]^T + [bq;0;bv]                               TF:319-321
-        LDIT_TRY(linear(y, C, P + pl.wqkv, P + pl.bqkv, big, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, stream, probe));
-        // y = softmax(q k^T / sqrt(D)) v, heads merged token-major                 TF:323-338
-        LDIT_RUN(probe, LDIT_K_ATTENTION,
-                 launch_attention(big, big + C, big + 2 * C, y, batch, g.T, g.H, g.D, 3 * C, 3 * C, 3 * C, C, scale, stream));
-        // h += lam1 (.) (y . Wo^T + bo)                                             TF:339, 432-434
-        LDIT_TRY(linear(y, C, P + pl.wo, P + pl.bo, h, C, M, C, C, EPI_SCALE_RESID, P + pl.lam1, h, nullptr, stream, probe));
-        // y = LN2(h)                                                               TF:438
-        LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm(h, P + pl.ln2_w, P + pl.ln2_b, y, M, C, cfg->ln_eps, stream));
-        // big[:, 0:F] = gelu(y . W1^T + b1)                                         TF:353-354
-        LDIT_TRY(linear(y, C, P + pl.w1, P + pl.b1, big, F, M, F, C, EPI_BIAS_GELU, nullptr, nullptr, nullptr, stream, probe));
-        // h += lam2 (.) (big . W2^T + b2)  (+ tap copy of the new hidden state)      TF:355, 440-442
         float *tap = tap_for(l + 1);
-        LDIT_TRY(linear(big, F, P + pl.w2, P + pl.b2, h, C, M, C, F, EPI_SCALE_RESID, P + pl.lam2, h, tap, stream, probe));
+        if (!bf16) {
+            // y = LN1(h)                                                               TF:426
+            LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm(h, F32(pl.ln1_w), F32(pl.ln1_b), y, M, C, cfg->ln_eps, stream));
+            // big[:, 0:3C] = y . [Wq;Wk;Wv]^T + [bq;0;bv]                               TF:319-321
+            LDIT_TRY(linear(y, C, F32(pl.wqkv), F32(pl.bqkv), big, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, stream, probe));
+            // y = softmax(q k^T / sqrt(D)) v, heads merged token-major                 TF:323-338
+            LDIT_RUN(probe, LDIT_K_ATTENTION,
+                     launch_attention(big, big + C, big + 2 * C, y, batch, g.T, g.H, g.D, 3 * C, 3 * C, 3 * C, C, scale, stream));
+            // h += lam1 (.) (y . Wo^T + bo)                                             TF:339, 432-434
+            LDIT_TRY(linear(y, C, F32(pl.wo), F32(pl.bo), h, C, M, C, C, EPI_SCALE_RESID, F32(pl.lam1), h, nullptr, stream, probe));
+            // y = LN2(h)                                                               TF:438
+            LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm(h, F32(pl.ln2_w), F32(pl.ln2_b), y, M, C, cfg->ln_eps, stream));
+            // big[:, 0:F] = gelu(y . W1^T + b1)                                         TF:353-354
+            LDIT_TRY(linear(y, C, F32(pl.w1), F32(pl.b1), big, F, M, F, C, EPI_BIAS_GELU, nullptr, nullptr, nullptr, stream, probe));
+            // h += lam2 (.) (big . W2^T + b2)  (+ tap copy of the new hidden state)      TF:355, 440-442
+            LDIT_TRY(linear(big, F, F32(pl.w2), F32(pl.b2), h, C, M, C, F, EPI_SCALE_RESID, F32(pl.lam2), h, tap, stream, probe));
+        } else {
+            // bf16 build: residual stream h, LayerNorm statistics, softmax and every accumulation stay fp32; the GEMM /
+            // attention operands (LN output, q|k|v, attention output, MLP hidden, the four weight matrices) are bf16.
+            char *yb = ws + wm.y, *bb = ws + wm.big;                 // bf16 buffers
+            LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bf16out(h, F32(pl.ln1_w), F32(pl.ln1_b), yb, M, C, cfg->ln_eps, stream));
+            LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16(yb, C, P + pl.wqkv, F32(pl.bqkv), bb, 3 * C, M, 3 * C, C, EPI_BIAS,
+                                                         nullptr, nullptr, nullptr, stream));
+            LDIT_RUN(probe, LDIT_K_ATTENTION,
+                     launch_attention_bf16(bb, bb + 2 * (size_t)C, bb + 4 * (size_t)C, yb, batch, g.T, g.H, g.D, 3 * C, 3 * C, 3 * C,
+                                           C, scale, stream));
+            LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16(yb, C, P + pl.wo, F32(pl.bo), h, C, M, C, C, EPI_SCALE_RESID, F32(pl.lam1),
+                                                         h, nullptr, stream));
+            LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bf16out(h, F32(pl.ln2_w), F32(pl.ln2_b), yb, M, C, cfg->ln_eps, stream));
+            LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16(yb, C, P + pl.w1, F32(pl.b1), bb, F, M, F, C, EPI_BIAS_GELU, nullptr,
+                                                         nullptr, nullptr, stream));
+            LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16(bb, F, P + pl.w2, F32(pl.b2), h, C, M, C, F, EPI_SCALE_RESID, F32(pl.lam2),
+                                                         h, tap, stream));
+        }
         if (tap) LDIT_TRY(extra_taps(l + 1, h, tap));
     }
     return LDIT_OK;
@@ -256,7 +282,7 @@ size_t ldit_packed_bytes(const ldit_cfg *cfg)
 {
     Geo g;
     if (geometry(cfg, g) != LDIT_OK) return 0;
-    return packed_map(g).total * sizeof(float);
+    return packed_map(g, cfg->dtype).total;
 }
 
 int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, size_t packed_bytes, ldit_stream stream_)
@@ -266,14 +292,21 @@ int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, 
     if (!w || !packed) return fail(LDIT_EINVAL, "null weights / packed pointer");
     if (!aligned16(packed)) return fail(LDIT_EINVAL, "packed must be 16-byte aligned");
     if (g.L && !w->layer) return fail(LDIT_EINVAL, "weights->layer is null");
-    const PackedMap pm = packed_map(g);
-    if (packed_bytes < pm.total * sizeof(float)) return fail(LDIT_EWORKSPACE, "packed buffer %zu bytes < required %zu", packed_bytes, pm.total * sizeof(float));
+    const PackedMap pm = packed_map(g, cfg->dtype);
+    if (packed_bytes < pm.total) return fail(LDIT_EWORKSPACE, "packed buffer %zu bytes < required %zu", packed_bytes, pm.total);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    float *P = static_cast<float *>(packed);
-    auto put = [&](size_t off, const void *src, size_t n, const char *what) -> int {
+    char *P = static_cast<char *>(packed);
+    const bool bf16 = cfg->dtype == LDIT_BF16;
+    auto put = [&](size_t off, const void *src, size_t n, const char *what) -> int {      // fp32 copy
         if (!src) return fail(LDIT_EINVAL, "weights: %s is null", what);
         LDIT_HIP_CHECK(hipMemcpyAsync(P + off, src, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
         return LDIT_OK;
+    };
+    auto put_mat = [&](size_t off, size_t elt_off, const void *src, size_t n, const char *what) -> int {   // matrix: fp32 or -> bf16
+        if (!src) return fail(LDIT_EINVAL, "weights: %s is null", what);
+        if (!bf16) return put(off + elt_off * 4, src, n, what);
+        if (!aligned16(src)) return fail(LDIT_EINVAL, "weights: %s must be 16-byte aligned", what);
+        return launch_cvt_bf16(static_cast<const float *>(src), P + off + elt_off * 2, n, stream);
     };
     const size_t C = g.C, F = g.F;
     LDIT_TRY(put(pm.patch_w, w->patch_w, C * g.Kp, "patch_w"));
@@ -285,19 +318,20 @@ int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, 
         const PackedLayer &pl = pm.layer[l];
         LDIT_TRY(put(pl.ln1_w, s.ln1_w, C, "ln1_w"));
         LDIT_TRY(put(pl.ln1_b, s.ln1_b, C, "ln1_b"));
-        LDIT_TRY(put(pl.wqkv, s.wq, C * C, "wq"));
-        LDIT_TRY(put(pl.wqkv + C * C, s.wk, C * C, "wk"));
-        LDIT_TRY(put(pl.wqkv + 2 * C * C, s.wv, C * C, "wv"));
+        LDIT_TRY(put_mat(pl.wqkv, 0, s.wq, C * C, "wq"));
+        LDIT_TRY(put_mat(pl.wqkv, C * C, s.wk, C * C, "wk"));
+        LDIT_TRY(put_mat(pl.wqkv, 2 * C * C, s.wv, C * C, "wv"));
         if (!s.bq || !s.bv) return fail(LDIT_EINVAL, "weights: bq / bv is null");
-        LDIT_TRY(launch_pack_qkv_bias(static_cast<const float *>(s.bq), static_cast<const float *>(s.bv), P + pl.bqkv, g.C, stream));
-        LDIT_TRY(put(pl.wo, s.wo, C * C, "wo"));
+        LDIT_TRY(launch_pack_qkv_bias(static_cast<const float *>(s.bq), static_cast<const float *>(s.bv),
+                                      reinterpret_cast<float *>(P + pl.bqkv), g.C, stream));
+        LDIT_TRY(put_mat(pl.wo, 0, s.wo, C * C, "wo"));
         LDIT_TRY(put(pl.bo, s.bo, C, "bo"));
         LDIT_TRY(put(pl.lam1, s.lam1, C, "lam1"));
         LDIT_TRY(put(pl.ln2_w, s.ln2_w, C, "ln2_w"));
         LDIT_TRY(put(pl.ln2_b, s.ln2_b, C, "ln2_b"));
-        LDIT_TRY(put(pl.w1, s.w1, F * C, "w1"));
+        LDIT_TRY(put_mat(pl.w1, 0, s.w1, F * C, "w1"));
         LDIT_TRY(put(pl.b1, s.b1, F, "b1"));
-        LDIT_TRY(put(pl.w2, s.w2, C * F, "w2"));
+        LDIT_TRY(put_mat(pl.w2, 0, s.w2, C * F, "w2"));
         LDIT_TRY(put(pl.b2, s.b2, C, "b2"));
         LDIT_TRY(put(pl.lam2, s.lam2, C, "lam2"));
     }
@@ -308,7 +342,7 @@ size_t ldit_workspace_bytes(const ldit_cfg *cfg, int32_t batch)
 {
     Geo g;
     if (batch <= 0 || geometry(cfg, g) != LDIT_OK) return 0;
-    return workspace_map(g, batch).total;
+    return workspace_map(g, batch, cfg->dtype).total;
 }
 
 int ldit_vit_forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batch, void *const *tap_out,
@@ -402,6 +436,18 @@ int ldit_linear_bf16(const void *X, int64_t lda, const void *W, const void *bias
     return launch_gemm_bf16(X, (int)lda, W, static_cast<const float *>(bias), Y, (int)ldy, (int)M, (int)N, (int)K, epilogue,
                             static_cast<const float *>(lam), static_cast<const float *>(R), static_cast<float *>(Y2),
                             static_cast<hipStream_t>(stream));
+}
+
+int ldit_attention_bf16(const void *Q, const void *K, const void *V, void *O, int64_t B, int64_t N, int64_t H, int64_t D,
+                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, ldit_stream stream)
+{
+    if (B <= 0 || N <= 0 || H <= 0) return fail(LDIT_EINVAL, "attention_bf16: empty problem");
+    const int64_t ldmax = ldq > ldk ? (ldq > ldv ? ldq : ldv) : (ldk > ldv ? ldk : ldv);
+    if (B * N * (ldmax > ldo ? ldmax : ldo) >= (1ll << 31) || B * H * ((N + 255) / 256) >= (1ll << 31))
+        return fail(LDIT_EUNSUPPORTED, "attention_bf16: operand exceeds 2^31 elements");
+    if (ldq < H * D || ldk < H * D || ldv < H * D || ldo < H * D) return fail(LDIT_EINVAL, "attention_bf16: row stride smaller than H*D");
+    return launch_attention_bf16(Q, K, V, O, (int)B, (int)N, (int)H, (int)D, (int)ldq, (int)ldk, (int)ldv, (int)ldo, scale,
+                                 static_cast<hipStream_t>(stream));
 }
 
 int ldit_cast_f32_bf16(const void *src, void *dst, int64_t n, ldit_stream stream)

@@ -17,9 +17,12 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 // VPL = float4 vectors per lane; handles C <= 256 * VPL
-template <int VPL>
+typedef __bf16 ln_bf16x4 __attribute__((ext_vector_type(4)));
+
+// OUT_BF16: the normalised row is rounded to bf16 (operand of the bf16 GEMMs); statistics and affine stay fp32.
+template <int VPL, bool OUT_BF16>
 __global__ void __launch_bounds__(256) layernorm_rows(const float *__restrict__ X, const float *__restrict__ g,
-                                                      const float *__restrict__ b, float *__restrict__ Y, int64_t rows,
+                                                      const float *__restrict__ b, void *__restrict__ Yv, int64_t rows,
                                                       int C, float eps)
 {
     const int lane = threadIdx.x & 63;
@@ -58,7 +61,6 @@ __global__ void __launch_bounds__(256) layernorm_rows(const float *__restrict__ 
     const float rstd = 1.0f / sqrtf(var + eps);
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g);
     const f32x4 *b4 = reinterpret_cast<const f32x4 *>(b);
-    f32x4 *y4 = reinterpret_cast<f32x4 *>(Y + row * C);
 #pragma unroll
     for (int u = 0; u < VPL; ++u) {
         const int idx = lane + 64 * u;
@@ -67,27 +69,44 @@ __global__ void __launch_bounds__(256) layernorm_rows(const float *__restrict__ 
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = v[u][e] * rstd * gg[e] + bb[e];
-            y4[idx] = o;
+            if (OUT_BF16) {
+                const ln_bf16x4 pk = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                reinterpret_cast<ln_bf16x4 *>(static_cast<__bf16 *>(Yv) + row * C)[idx] = pk;
+            } else {
+                reinterpret_cast<f32x4 *>(static_cast<float *>(Yv) + row * C)[idx] = o;
+            }
         }
     }
 }
 
 }  // namespace
 
-int launch_layernorm(const float *X, const float *g, const float *b, float *Y, int64_t rows, int C, float eps,
-                     hipStream_t stream)
+template <bool OUT_BF16>
+static int launch_ln(const float *X, const float *g, const float *b, void *Y, int64_t rows, int C, float eps, hipStream_t stream)
 {
     if (rows <= 0 || C <= 0) return fail(LDIT_EINVAL, "layernorm: empty problem");
     if (!X || !g || !b || !Y) return fail(LDIT_EINVAL, "layernorm: null operand");
     if (C & 3) return fail(LDIT_EUNSUPPORTED, "layernorm: C=%d must be a multiple of 4", C);
     if (C > 4096) return fail(LDIT_EUNSUPPORTED, "layernorm: C=%d exceeds 4096", C);
-    if (!aligned16(X) || !aligned16(Y) || !aligned16(g) || !aligned16(b)) return fail(LDIT_EINVAL, "layernorm: operands must be 16-byte aligned");
+    if (!aligned16(X) || (reinterpret_cast<uintptr_t>(Y) & 7u) || !aligned16(g) || !aligned16(b)) return fail(LDIT_EINVAL, "layernorm: operands must be 16-byte aligned");
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    if (C <= 256) hipLaunchKernelGGL(layernorm_rows<1>, grid, block, 0, stream, X, g, b, Y, rows, C, eps);
-    else if (C <= 1024) hipLaunchKernelGGL(layernorm_rows<4>, grid, block, 0, stream, X, g, b, Y, rows, C, eps);
-    else hipLaunchKernelGGL(layernorm_rows<16>, grid, block, 0, stream, X, g, b, Y, rows, C, eps);
+    if (C <= 256) hipLaunchKernelGGL((layernorm_rows<1, OUT_BF16>), grid, block, 0, stream, X, g, b, Y, rows, C, eps);
+    else if (C <= 1024) hipLaunchKernelGGL((layernorm_rows<4, OUT_BF16>), grid, block, 0, stream, X, g, b, Y, rows, C, eps);
+    else hipLaunchKernelGGL((layernorm_rows<16, OUT_BF16>), grid, block, 0, stream, X, g, b, Y, rows, C, eps);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
+}
+
+int launch_layernorm(const float *X, const float *g, const float *b, float *Y, int64_t rows, int C, float eps,
+                     hipStream_t stream)
+{
+    return launch_ln<false>(X, g, b, Y, rows, C, eps, stream);
+}
+
+int launch_layernorm_bf16out(const float *X, const float *g, const float *b, void *Y, int64_t rows, int C, float eps,
+                             hipStream_t stream)
+{
+    return launch_ln<true>(X, g, b, Y, rows, C, eps, stream);
 }
 
 }  // namespace ldit

@@ -54,6 +54,10 @@ int launch_gemm_panel(const GemmArgs &a, int epi, int amode, hipStream_t stream)
 // ---- other kernels ---------------------------------------------------------------------------------------------
 int launch_layernorm(const float *X, const float *g, const float *b, float *Y, int64_t rows, int C, float eps,
                      hipStream_t stream);
+int launch_layernorm_bf16out(const float *X, const float *g, const float *b, void *Y, int64_t rows, int C, float eps,
+                             hipStream_t stream);
+int launch_attention_bf16(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ldq, int ldk,
+                          int ldv, int ldo, float scale, hipStream_t stream);
 int launch_attention(const float *Q, const float *K, const float *V, float *O, int B, int N, int H, int D, int ldq,
                      int ldk, int ldv, int ldo, float scale, hipStream_t stream);
 int launch_cls_rows(const float *cls, const float *pos, float *out, int B, int tokens, int C, hipStream_t stream);

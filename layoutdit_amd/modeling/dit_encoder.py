@@ -51,8 +51,13 @@ class DiTEncoderOutput:
 
 
 class DiTEncoder(nn.Module):
-    def __init__(self, config: Optional[DiTConfig] = None):
+    def __init__(self, config: Optional[DiTConfig] = None, compute_dtype: str = "f32"):
+        """``compute_dtype``: ``"f32"`` (exact-fp32 MFMA, the parity path) or ``"bf16"`` (bf16 GEMM / attention operands
+        with fp32 accumulation, residual stream, LayerNorm and softmax; parameters and returned taps stay fp32)."""
         super().__init__()
+        if compute_dtype not in ("f32", "bf16"):
+            raise ValueError(f"compute_dtype {compute_dtype!r}: expected 'f32' or 'bf16'")
+        self.compute_dtype = compute_dtype
         self.config = config or DiTConfig()
         cfg = self.config
         Cc, Fm, p, ch = cfg.hidden_size, cfg.intermediate_size, cfg.patch_size, cfg.num_channels
@@ -124,7 +129,8 @@ class DiTEncoder(nn.Module):
         cfg = self.config
         c = _lib.LditCfg(hidden=cfg.hidden_size, layers=cfg.num_hidden_layers, heads=cfg.num_attention_heads,
                          mlp=cfg.intermediate_size, patch=cfg.patch_size, in_ch=cfg.num_channels, img_h=img_h,
-                         img_w=img_w, n_taps=len(taps), ln_eps=cfg.layer_norm_eps, dtype=0, flags=0)
+                         img_w=img_w, n_taps=len(taps), ln_eps=cfg.layer_norm_eps,
+                         dtype=_lib.DTYPE_BF16 if self.compute_dtype == "bf16" else _lib.DTYPE_F32, flags=0)
         for i, t in enumerate(taps):
             c.taps[i] = t
         return c
@@ -151,7 +157,7 @@ class DiTEncoder(nn.Module):
 
     def _pack(self, lcfg: _lib.LditCfg, pos: torch.Tensor, device: torch.device) -> torch.Tensor:
         params = [p for p in self.parameters()]
-        key = (str(device), lcfg.img_h, lcfg.img_w, pos.data_ptr(),
+        key = (str(device), lcfg.img_h, lcfg.img_w, lcfg.dtype, pos.data_ptr(),
                tuple((p.data_ptr(), p._version) for p in params))
         if self._packed is not None and self._packed_key == key:
             return self._packed

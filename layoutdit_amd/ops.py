@@ -148,3 +148,17 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     _lib.check(lib.ldit_linear_bf16(_ptr(x), K, _ptr(weight), _ptr(bias), _ptr(out), N, M, N, K, epilogue, _ptr(lam),
                                     _ptr(residual), _ptr(out2), _stream()))
     return out
+
+
+def attention_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None) -> torch.Tensor:
+    """bf16 fused attention; ``q, k, v``: bf16 [B, N, H*D] token-major (column slices of a fused tensor are fine)."""
+    lib = _lib.load()
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or t.stride(-1) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+            raise ValueError(f"{n}: expected GPU bfloat16 [B,N,H*D] with unit last stride and dense batch stride")
+    B, N, HD = q.shape
+    D = HD // heads
+    o = torch.empty((B, N, HD), device=q.device, dtype=torch.bfloat16)
+    _lib.check(lib.ldit_attention_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, N, heads, D, q.stride(1), k.stride(1),
+                                       v.stride(1), HD, float(D ** -0.5 if scale is None else scale), _stream()))
+    return o
