@@ -139,15 +139,19 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
     }
 }
 
-template <int TM, int TN, int EPI>
-__global__ void __launch_bounds__(256) gemm_bf16_mfma(const GemmArgsH p)
+// WM x WN waves per workgroup, each owning TM x TN 32x32 tiles.  2 x 4 waves (512 threads, two waves per SIMD) let one
+// wave's MFMAs cover the other's LDS reads, DMA issue and barrier waits.
+template <int WM, int WN, int TM, int TN, int EPI>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(const GemmArgsH p)
 {
-    constexpr int BM = 64 * TM, BN = 64 * TN, ROWS = BM + BN, NLD = ROWS / 32;
+    constexpr int NWAVES = WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, ROWS = BM + BN, NLD = ROWS / (8 * NWAVES);
+    static_assert(ROWS % (8 * NWAVES) == 0 && BM % 8 == 0, "DMA pieces must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int c32 = lane & 31, h = lane >> 5;
 
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
@@ -162,9 +166,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_mfma(const GemmArgsH p)
     unsigned src[NLD];   // element (bf16) offsets
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-        const int row = 8 * (wave + 4 * u) + (lane >> 3);
+        const int row = 8 * (wave + NWAVES * u) + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        if (8 * (wave + 4 * u) < BM) {
+        if (8 * (wave + NWAVES * u) < BM) {
             int gm = m0 + row;
             gm = gm < p.M ? gm : p.M - 1;
             src[u] = (unsigned)gm * (unsigned)p.lda + c * 8;
@@ -178,7 +182,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_mfma(const GemmArgsH p)
         char *base = smem + stage * (ROWS * ROWB);
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
-            const int piece = wave + 4 * u;
+            const int piece = wave + NWAVES * u;
             const bf16_t *opnd = 8 * piece < BM ? p.A : p.W;
             glds16h(opnd + (src[u] + (unsigned)k0), base + piece * 1024);
         }
@@ -238,20 +242,20 @@ __global__ void __launch_bounds__(256) gemm_bf16_mfma(const GemmArgsH p)
     else store_h<TM, TN, EPI, true>(p, acc, mw, nw, lane);
 }
 
-template <int TM, int TN, int EPI>
+template <int WM, int WN, int TM, int TN, int EPI>
 int launch_h(const GemmArgsH &a, hipStream_t stream)
 {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int lds = 2 * (BM + BN) * ROWB;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    auto kern = gemm_bf16_mfma<TM, TN, EPI>;
+    auto kern = gemm_bf16_mfma<WM, WN, TM, TN, EPI>;
     static bool attr_set = false;
     if (!attr_set) {
         LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), lds, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }
@@ -260,7 +264,7 @@ template <int EPI>
 int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
 {
     struct Cand { int bm, bn, id; double eff; };
-    const Cand cands[3] = {{256, 256, 0, 1.0}, {256, 128, 1, 0.8}, {128, 128, 2, 0.55}};
+    const Cand cands[4] = {{256, 256, 3, 1.0}, {256, 256, 0, 0.8}, {256, 128, 1, 0.7}, {128, 128, 2, 0.5}};
     double best = -1.0;
     int pick = 2;
     for (const Cand &c : cands) {
@@ -270,12 +274,13 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
         if (best < 0 || cost < best) { best = cost; pick = c.id; }
     }
     if (const char *force = getenv("LDIT_GEMM_BF16_TILE")) {
-        if (force[0] >= '0' && force[0] <= '2' && force[1] == 0) pick = force[0] - '0';
+        if (force[0] >= '0' && force[0] <= '3' && force[1] == 0) pick = force[0] - '0';
     }
     switch (pick) {
-        case 0: return launch_h<4, 4, EPI>(a, stream);
-        case 1: return launch_h<4, 2, EPI>(a, stream);
-        default: return launch_h<2, 2, EPI>(a, stream);
+        case 3: return launch_h<2, 4, 4, 2, EPI>(a, stream);     // 256 x 256, 8 waves (2 per SIMD)
+        case 0: return launch_h<2, 2, 4, 4, EPI>(a, stream);     // 256 x 256, 4 waves
+        case 1: return launch_h<2, 2, 4, 2, EPI>(a, stream);     // 256 x 128, 4 waves
+        default: return launch_h<2, 2, 2, 2, EPI>(a, stream);    // 128 x 128, 4 waves
     }
 }
 
