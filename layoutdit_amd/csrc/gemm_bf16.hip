@@ -264,6 +264,8 @@ template <int EPI>
 int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
 {
     struct Cand { int bm, bn, id; double eff; };
+    // (a 288 x 256 four-wave "panel" instantiation <1,4,9,2> fixes the tile quantisation at M = 16 x 1025 but needs the
+    //  pinned DMA/read schedule of gemm_panel_f32.hip to pay off: naive it spills and ran 439 vs 599 TFLOP/s)
     const Cand cands[4] = {{256, 256, 3, 1.0}, {256, 256, 0, 0.8}, {256, 128, 1, 0.7}, {128, 128, 2, 0.5}};
     double best = -1.0;
     int pick = 2;
