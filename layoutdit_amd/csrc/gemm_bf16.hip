@@ -33,27 +33,6 @@ __device__ __forceinline__ void glds16h(const void *gsrc, char *lds_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ float erf_fasth(float a)
-{
-    const float t = fabsf(a), s = a * a;
-    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
-    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
-    r = fmaf(r, s, u);
-    r = fmaf(r, t, -1.06777877e-1f);
-    r = fmaf(r, t, -6.34846687e-1f);
-    r = fmaf(r, t, -1.28717512e-1f);
-    r = fmaf(r, t, -t);
-    const float big = copysignf(1.0f - __expf(r), a);
-    float q = -5.96761703e-4f;
-    q = fmaf(q, s, 4.99119423e-3f);
-    q = fmaf(q, s, -2.67681349e-2f);
-    q = fmaf(q, s, 1.12819925e-1f);
-    q = fmaf(q, s, -3.76125336e-1f);
-    q = fmaf(q, s, 1.28379166e-1f);
-    const float small = fmaf(q, a, a);
-    return t > 0.927734375f ? big : small;
-}
-__device__ __forceinline__ float geluh(float v) { return 0.5f * v * (1.0f + erf_fasth(v * 0.70710678118654752440f)); }
 
 struct GemmArgsH {
     const bf16_t *A;     // [M, K] bf16
@@ -108,7 +87,7 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float t = acc[i][j][4 * g + e] + bias[g][e];
-                    if (EPI == EPI_BIAS_GELU) t = geluh(t);
+                    if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
                     if (EPI == EPI_SCALE_RESID) t = res[g][e] + lam[g][e] * t;
                     v[e] = t;
                 }

@@ -32,31 +32,6 @@ __device__ __forceinline__ void glds16(const float *gsrc, char *lds_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-// erf to < 1 ulp in ~25 instructions, branch-free (both ranges evaluated, one selected): odd polynomial in x below
-// 0.927734375, 1 - exp(poly(|x|)) above (coefficients: N. Juffa's single-precision erff).  libdevice's erff costs
-// ~90 instructions per call with divergent ranges - 28 us per fc1 tile round when it sat in the epilogue.
-__device__ __forceinline__ float erf_fast(float a)
-{
-    const float t = fabsf(a), s = a * a;
-    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
-    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
-    r = fmaf(r, s, u);
-    r = fmaf(r, t, -1.06777877e-1f);
-    r = fmaf(r, t, -6.34846687e-1f);
-    r = fmaf(r, t, -1.28717512e-1f);
-    r = fmaf(r, t, -t);
-    const float big = copysignf(1.0f - __expf(r), a);
-    float q = -5.96761703e-4f;
-    q = fmaf(q, s, 4.99119423e-3f);
-    q = fmaf(q, s, -2.67681349e-2f);
-    q = fmaf(q, s, 1.12819925e-1f);
-    q = fmaf(q, s, -3.76125336e-1f);
-    q = fmaf(q, s, 1.28379166e-1f);
-    const float small = fmaf(q, a, a);
-    return t > 0.927734375f ? big : small;
-}
-
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f)); }
 
 // Epilogue of one wave: register r of lanes 0-31 / 32-63 = 128 contiguous bytes of output rows 8(r>>2)+(r&3) / +4 of
 // each 32x32 tile.  CHECK = false for blocks wholly inside the matrix: no per-element bounds work at all.

@@ -41,28 +41,6 @@ __device__ __forceinline__ void glds16p(const float *gsrc, char *lds_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
-// erf to < 1 ulp, branch-free (see gemm_f32.hip)
-__device__ __forceinline__ float erf_fastp(float a)
-{
-    const float t = fabsf(a), s = a * a;
-    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
-    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
-    r = fmaf(r, s, u);
-    r = fmaf(r, t, -1.06777877e-1f);
-    r = fmaf(r, t, -6.34846687e-1f);
-    r = fmaf(r, t, -1.28717512e-1f);
-    r = fmaf(r, t, -t);
-    const float big = copysignf(1.0f - __expf(r), a);
-    float q = -5.96761703e-4f;
-    q = fmaf(q, s, 4.99119423e-3f);
-    q = fmaf(q, s, -2.67681349e-2f);
-    q = fmaf(q, s, 1.12819925e-1f);
-    q = fmaf(q, s, -3.76125336e-1f);
-    q = fmaf(q, s, 1.28379166e-1f);
-    const float small = fmaf(q, a, a);
-    return t > 0.927734375f ? big : small;
-}
-__device__ __forceinline__ float gelup(float v) { return 0.5f * v * (1.0f + erf_fastp(v * 0.70710678118654752440f)); }
 
 // One float4 of the output: row m, columns n..n+3.  VEC: 16-B accesses, no bounds checks (block inside the matrix,
 // ldy % 4 == 0); otherwise element-wise with checks.  `res` = residual values already fetched (EPI_SCALE_RESID).
@@ -86,7 +64,7 @@ __device__ __forceinline__ void emit4(const GemmArgs &p, int m, int n, f32x4 acc
     for (int r = 0; r < 4; ++r) {
         float t = acc[r] + bias[r];
         if (EPI == EPI_EMBED) t += pos[r];
-        if (EPI == EPI_BIAS_GELU) t = gelup(t);
+        if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
         if (EPI == EPI_SCALE_RESID) t = res[r] + lam[r] * t;
         v[r] = t;
     }

@@ -26,6 +26,33 @@ int fail(int code, const char *fmt, ...);
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// erf to < 1 ulp in ~25 instructions, branch-free (both ranges evaluated, one selected): odd polynomial in x below
+// 0.927734375, 1 - exp(poly(|x|)) above (coefficients: N. Juffa's single-precision erff).  libdevice's erff costs
+// ~90 instructions per call with divergent ranges - 28 us per fc1 tile round when it sat in the GEMM epilogue.
+__device__ __forceinline__ float erf_fast(float a)
+{
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    const float big = copysignf(1.0f - __expf(r), a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    const float small = fmaf(q, a, a);
+    return t > 0.927734375f ? big : small;
+}
+
+// exact (erf) GELU of TF:activations.py:70-89
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f)); }
+
 // ---- GEMM ----------------------------------------------------------------------------------------------------
 enum AMode { A_ROWMAJOR = 0, A_PATCH = 1 };
 enum Epi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_SCALE_RESID = 2, EPI_EMBED = 3 };
