@@ -193,12 +193,12 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
                 const int gy = pi / p.gw, gx = pi - gy * p.gw;
                 src[u] = (unsigned)b * (unsigned)p.lda + (unsigned)(gy * p.patch * p.img_w + gx * p.patch);
             } else {
-                src[u] = (unsigned)gm * (unsigned)p.lda + c * 4;
+                src[u] = ((unsigned)gm * (unsigned)p.lda + c * 4) * 4u;      // BYTE offset (row-major operands)
             }
         } else {
             int gn = n0 + row - BM;
             gn = gn < p.N ? gn : p.N - 1;
-            src[u] = (unsigned)gn * (unsigned)p.K + c * 4;
+            src[u] = ((unsigned)gn * (unsigned)p.K + c * 4) * 4u;              // BYTE offset
         }
     }
     auto issue = [&](int stage, int k0) {
@@ -215,7 +215,9 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
                 const int ch = k / pp, rem = k - ch * pp, dy = rem / p.patch, dx = rem - dy * p.patch;
                 g = opnd + (src[u] + (unsigned)((ch * p.img_h + dy) * p.img_w + dx));
             } else {
-                g = opnd + (src[u] + (unsigned)k0);
+                // uniform base advanced by k0 (SALU) + fixed per-lane byte offset: the DMA is issued in its
+                // saddr + 32-bit voffset form with no per-piece VALU address arithmetic
+                g = reinterpret_cast<const float *>(reinterpret_cast<const char *>(opnd + k0) + src[u]);
             }
             glds16p(g, base + piece * 1024);
         }

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(ROOT, "layoutdit_amd", "csrc", "build", "libldit_hip_dbg.so"))
+lib = C.CDLL(os.path.join(ROOT, "layoutdit_amd", "csrc", "build", os.environ.get("DBGLIB", "libldit_hip_dbg.so")))
 lib.ldit_dbg_linear_stamps.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 4
 dev = "cuda:0"
 M = 12608
