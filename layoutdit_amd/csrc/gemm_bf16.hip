@@ -239,9 +239,232 @@ int launch_h(const GemmArgsH &a, hipStream_t stream)
     return LDIT_OK;
 }
 
+// ---- ring kernel: 256 x 256 tile, 8 waves (2 x 4, two per SIMD), BK = 32, FOUR LDS stages, prefetch distance 3 ------
+// The simple two-stage loop above waits for vmcnt(0) at every hand-over with one tile in flight, and at bf16 MFMA rates
+// (a k-tile is ~2 k cycles per SIMD) that exposes most of the L2 latency.  Here three k-tiles are always in flight: the
+// hand-over waits with a COUNTED vmcnt (tile kt landed, tiles kt+1 and kt+2 still flying), uses a raw s_barrier (a
+// __syncthreads() would drain the DMA queue), and immediately issues tile kt+3 into the stage every wave has just left.
+// LDS rows are 64 B (32 bf16): one DMA piece = 16 rows, 16-B chunk XOR-swizzled with (row>>2)&3 on the source address
+// and on the read (16 consecutive rows x one chunk -> 16 distinct 16-B slots of the four-row bank line).
+template <int EPI>
+__global__ void __launch_bounds__(512, 2) gemm_bf16_ring(const GemmArgsH p)
+{
+    constexpr int BM = 256, BN = 256, ROWS = BM + BN, BK = 32, RB = 64, STAGE_BYTES = ROWS * RB;   // 4 stages
+    constexpr int NW = 8, NLD = ROWS / 16 / NW;          // 4 DMA pieces per wave per k-tile
+    constexpr int TM = 4, TN = 2;                        // wave tile 128 x 64
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int c32 = lane & 31, h = lane >> 5;
+
+    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+    const int ntiles = nbm * nbn;
+    int tile;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = ntiles >> 3, rr = ntiles & 7;
+        tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+
+    unsigned src[NLD];   // bf16 element offsets
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int piece = wave + NW * u, row = 16 * piece + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        if (16 * piece < BM) {
+            int gm = m0 + row;
+            gm = gm < p.M ? gm : p.M - 1;
+            src[u] = (unsigned)gm * (unsigned)p.lda + c * 8;
+        } else {
+            int gn = n0 + row - BM;
+            gn = gn < p.N ? gn : p.N - 1;
+            src[u] = (unsigned)gn * (unsigned)p.K + c * 8;
+        }
+    }
+    auto issue = [&](int stage, int k0) {
+        char *base = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int piece = wave + NW * u;
+            const bf16_t *opnd = 16 * piece < BM ? p.A : p.W;
+            glds16h(opnd + (src[u] + (unsigned)k0), base + piece * 1024);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = p.K / BK;
+    const int sw = (c32 >> 2) & 3;
+    const int a_row = (wm * TM * 32 + c32) * RB, b_row = (BM + wn * TN * 32 + c32) * RB;
+
+    // prologue: tiles 0, 1, 2 in flight (clamped re-fetches when K is shorter; they are harmless and counted)
+    issue(0, 0);
+    issue(1, (nk > 1 ? 1 : nk - 1) * BK);
+    issue(2, (nk > 2 ? 2 : nk - 1) * BK);
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed once at most the 2*NLD youngest DMA pieces of this wave are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // stage (kt+3)&3 == (kt-1)&3 was read in the previous iteration; every wave has passed the barrier since.
+        // Past the end the last tile is re-fetched so that the wait above keeps its meaning; drained before the epilogue.
+        issue((kt + 3) & 3, (kt + 3 < nk ? kt + 3 : nk - 1) * BK);
+        const char *st = smem + (kt & 3) * STAGE_BYTES;
+        bf16x8 xa[2][TM], wb[2][TN];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const char *base = st + (((2 * s + h) ^ sw) * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xa[s][i] = *reinterpret_cast<const bf16x8 *>(base + a_row + i * 32 * RB);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wb[s][j] = *reinterpret_cast<const bf16x8 *>(base + b_row + j * 32 * RB);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[s][j], xa[s][i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail re-fetches must not outlive the LDS allocation
+
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
+    const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
+    if (interior) store_h<TM, TN, EPI, false>(p, acc, mw, nw, lane);
+    else store_h<TM, TN, EPI, true>(p, acc, mw, nw, lane);
+}
+
+template <int EPI>
+int launch_ring(const GemmArgsH &a, hipStream_t stream)
+{
+    constexpr int lds = 4 * 512 * 64;
+    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    auto kern = gemm_bf16_ring<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, stream, a);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+// ---- skinny kernel: up to 64 rows (the ragged tail peeled off by launch_gemm_bf16) -----------------------------------
+// A 16-row remainder on a 128 x 128 tile is a serial K loop of ~0.4 us per k-tile (24 us at K = 4096) with 8 workgroups
+// on the machine.  Here a workgroup owns 64 rows x 64 columns and its EIGHT waves split K: every wave multiplies the
+// whole 64 x 64 tile over K/8 with fragments loaded straight from global memory (no LDS staging: nothing is reused),
+// the eight partial tiles are summed through LDS in a fixed order, then the usual epilogue runs on 8 elements per thread.
+template <int EPI>
+__global__ void __launch_bounds__(512, 2) gemm_bf16_skinny(const GemmArgsH p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *part = reinterpret_cast<float *>(smem);            // [8 waves][64 rows][64 cols]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c32 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 64;
+    const int kslice = p.K / 8, k0 = wave * kslice;
+
+    int ra[2], rw[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = 32 * t + c32, n = n0 + 32 * t + c32;
+        ra[t] = m < p.M ? m : p.M - 1;
+        rw[t] = n < p.N ? n : p.N - 1;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    const bf16_t *ap[2] = {p.A + (size_t)ra[0] * p.lda + k0 + 8 * h, p.A + (size_t)ra[1] * p.lda + k0 + 8 * h};
+    const bf16_t *wp[2] = {p.W + (size_t)rw[0] * p.K + k0 + 8 * h, p.W + (size_t)rw[1] * p.K + k0 + 8 * h};
+    for (int s = 0; s < kslice / 16; ++s) {
+        bf16x8 xa[2], wb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            xa[t] = *reinterpret_cast<const bf16x8 *>(ap[t] + 16 * s);
+            wb[t] = *reinterpret_cast<const bf16x8 *>(wp[t] + 16 * s);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+    }
+    // partial tile of this wave -> LDS: acc[i][j][4g+e] = (row 32i + c32, col 32j + 8g + 4h + e)
+    float *mine = part + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(mine + (32 * i + c32) * 64 + 32 * j + 8 * g + 4 * h) = v;
+            }
+    __syncthreads();
+    // fixed-order sum of the eight partials; thread t owns row t / 8, columns 8 (t % 8) .. +7
+    const int row = tid >> 3, col = (tid & 7) * 8;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(part + w * 4096 + row * 64 + col);
+        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(part + w * 4096 + row * 64 + col + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s0[e] += a0[e]; s1[e] += a1[e]; }
+    }
+    if (row >= p.M) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int n = n0 + col + e;
+        if (n >= p.N) break;
+        float t = (e < 4 ? s0[e] : s1[e - 4]) + (p.bias ? p.bias[n] : 0.0f);
+        const size_t o = (size_t)row * p.ldy + n;
+        if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
+        if (EPI == EPI_SCALE_RESID) {
+            t = p.R[o] + p.lam[n] * t;
+            static_cast<float *>(p.Y)[o] = t;
+            if (p.Y2) p.Y2[o] = t;
+        } else {
+            static_cast<bf16_t *>(p.Y)[o] = (bf16_t)t;
+        }
+    }
+}
+
+template <int EPI>
+int launch_skinny(const GemmArgsH &a, hipStream_t stream)
+{
+    constexpr int lds = 8 * 4096 * 4;
+    auto kern = gemm_bf16_skinny<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((a.N + 63) / 64), dim3(512), lds, stream, a);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
 template <int EPI>
 int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
 {
+    if (a.M <= 64 && a.K % 128 == 0 && !getenv("LDIT_GEMM_BF16_TILE")) return launch_skinny<EPI>(a, stream);
     struct Cand { int bm, bn, id; double eff; };
     // (a 288 x 256 four-wave "panel" instantiation <1,4,9,2> fixes the tile quantisation at M = 16 x 1025 but needs the
     //  pinned DMA/read schedule of gemm_panel_f32.hip to pay off: naive it spills and ran 439 vs 599 TFLOP/s)
@@ -255,7 +478,11 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
         if (best < 0 || cost < best) { best = cost; pick = c.id; }
     }
     if (const char *force = getenv("LDIT_GEMM_BF16_TILE")) {
-        if (force[0] >= '0' && force[0] <= '3' && force[1] == 0) pick = force[0] - '0';
+        if (force[0] >= '0' && force[0] <= '4' && force[1] == 0) pick = force[0] - '0';
+    }
+    if (pick == 4) {
+        if (a.K % 32) return fail(LDIT_EUNSUPPORTED, "gemm_bf16 ring: K must be a multiple of 32");
+        return launch_ring<EPI>(a, stream);
     }
     switch (pick) {
         case 3: return launch_h<2, 4, 4, 2, EPI>(a, stream);     // 256 x 256, 8 waves (2 per SIMD)
@@ -280,8 +507,31 @@ __global__ void __launch_bounds__(256) cvt_f32_bf16(const float *__restrict__ sr
 
 }  // namespace
 
+static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K,
+                                int epi, const float *lam, const float *R, float *Y2, hipStream_t stream);
+
+// A few rows past a multiple of the 256-row tile (M = 16 x 1025 = 64 x 256 + 16) would cost a whole extra row of
+// workgroups - a full extra round of the machine for N = 1024.  Such a ragged tail is peeled off into a second, tiny
+// launch on the 128 x 128 tiling; the main part then fills 256 CUs in whole rounds.
 int launch_gemm_bf16(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
                      const float *lam, const float *R, float *Y2, hipStream_t stream)
+{
+    const int rem = M % 256;
+    if (M >= 1024 && rem != 0 && rem <= 64 && !getenv("LDIT_GEMM_BF16_TILE")) {
+        const int main_rows = M - rem;
+        const size_t out_elt = epi == EPI_SCALE_RESID ? 4 : 2;
+        int rc = launch_gemm_bf16_one(A, lda, W, bias, Y, ldy, main_rows, N, K, epi, lam, R, Y2, stream);
+        if (rc != LDIT_OK) return rc;
+        const char *At = static_cast<const char *>(A) + (size_t)main_rows * lda * 2;
+        char *Yt = static_cast<char *>(Y) + (size_t)main_rows * ldy * out_elt;
+        return launch_gemm_bf16_one(At, lda, W, bias, Yt, ldy, rem, N, K, epi, lam, R ? R + (size_t)main_rows * ldy : nullptr,
+                                    Y2 ? Y2 + (size_t)main_rows * ldy : nullptr, stream);
+    }
+    return launch_gemm_bf16_one(A, lda, W, bias, Y, ldy, M, N, K, epi, lam, R, Y2, stream);
+}
+
+static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K,
+                                int epi, const float *lam, const float *R, float *Y2, hipStream_t stream)
 {
     if (M <= 0 || N <= 0 || K <= 0) return fail(LDIT_EINVAL, "gemm_bf16: empty problem");
     if (K % BKB) return fail(LDIT_EUNSUPPORTED, "gemm_bf16: K=%d must be a multiple of %d", K, BKB);

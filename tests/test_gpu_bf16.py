@@ -40,7 +40,7 @@ def test_cast_matches_torch_round_to_nearest_even():
     assert torch.equal(got, torch.from_numpy(x).to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("tile", ["auto", "0", "1", "2", "3"])
+@pytest.mark.parametrize("tile", ["auto", "0", "1", "2", "3", "4"])
 @pytest.mark.parametrize("M,N,K", [(37, 50, 64), (394, 576, 192), (1025, 1024, 1024), (513, 3072, 768), (300, 768, 4096)])
 def test_linear_bf16_bias(M, N, K, tile):
     if tile != "auto":
@@ -53,7 +53,7 @@ def test_linear_bf16_bias(M, N, K, tile):
     assert max_rel(y, ref) < 1.6e-2        # <= one bf16 ulp (2^-8) of max(|ref|, 1), plus accumulation noise
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "3", "4"])
 def test_linear_bf16_gelu_and_residual(tile):
     os.environ["LDIT_GEMM_BF16_TILE"] = tile
     M, N, K = 394, 320, 128
@@ -122,3 +122,35 @@ def test_forward_bf16_vs_fp32_oracle(geom, size, B):
         h = out.hidden_states[t]
         assert h.dtype == torch.float32
         assert rel_l2(h.cpu().numpy(), r) < 2e-2, t
+
+
+def test_linear_bf16_ragged_tail_is_peeled():
+    """M = 4 x 256 + 16 takes the two-launch path (main part on 256-row tiles + a peeled 16-row tail)."""
+    M, N, K = 1040, 512, 256
+    x, w, b = _bf16_round(_rand(40, M, K)), _bf16_round(_rand(41, N, K, scale=0.05)), _rand(42, N, scale=0.1)
+    xd, wd = torch.from_numpy(x).to(DEV).to(torch.bfloat16), torch.from_numpy(w).to(DEV).to(torch.bfloat16)
+    y = ops.linear_bf16(xd, wd, torch.from_numpy(b).to(DEV)).float().cpu().numpy()
+    assert rel_l2(y, oracle.linear(x, w, b)) < 3e-3
+    lam, r = np.abs(_rand(43, N)) * 0.3 + 0.05, _rand(44, M, N)
+    h = torch.from_numpy(r).to(DEV)
+    tap = torch.zeros((M, N), device=DEV)
+    ops.linear_bf16(xd, wd, torch.from_numpy(b).to(DEV), epilogue=_lib.EPI_SCALE_RESID, lam=torch.from_numpy(lam).to(DEV),
+                    residual=h, out=h, out2=tap)
+    ref = (r.astype(np.float64) + lam.astype(np.float64) * oracle.linear(x, w, b).astype(np.float64)).astype(np.float32)
+    assert rel_l2(h.cpu().numpy(), ref) < 1e-5
+    np.testing.assert_array_equal(tap.cpu().numpy(), h.cpu().numpy())
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 1024, 1024), (1, 128, 128), (64, 320, 4096), (37, 200, 256)])
+def test_linear_bf16_skinny(M, N, K):
+    """<= 64 rows: the split-K skinny kernel (eight waves share K, fixed-order LDS reduction)."""
+    x, w, b = _bf16_round(_rand(50, M, K)), _bf16_round(_rand(51, N, K, scale=0.05)), _rand(52, N, scale=0.1)
+    xd, wd, bd = (torch.from_numpy(x).to(DEV).to(torch.bfloat16), torch.from_numpy(w).to(DEV).to(torch.bfloat16),
+                  torch.from_numpy(b).to(DEV))
+    y = ops.linear_bf16(xd, wd, bd, epilogue=_lib.EPI_BIAS_GELU).float().cpu().numpy()
+    assert rel_l2(y, oracle.gelu(oracle.linear(x, w, b))) < 3e-3
+    lam, r = np.abs(_rand(53, N)) * 0.3 + 0.05, _rand(54, M, N)
+    h = torch.from_numpy(r).to(DEV)
+    ops.linear_bf16(xd, wd, bd, epilogue=_lib.EPI_SCALE_RESID, lam=torch.from_numpy(lam).to(DEV), residual=h, out=h)
+    ref = (r.astype(np.float64) + lam.astype(np.float64) * oracle.linear(x, w, b).astype(np.float64)).astype(np.float32)
+    assert rel_l2(h.cpu().numpy(), ref) < 1e-5
