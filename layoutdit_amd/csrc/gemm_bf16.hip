@@ -193,27 +193,95 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
     };
 
-    // same pipeline as the fp32 kernels: step s+1 fragments are read under step s MFMAs, the DMA of tile kt+1 is issued
-    // in step 0, the hand-over barrier sits in front of the last step's MFMAs.
+    // Pinned pipeline (sched_group_barrier), four 16-deep steps per 64-deep k-tile:
+    //   step s multiplies fragments read during step s-1 while the fragments of step s+1 are read, ONE LDS read or DMA
+    //   piece per MFMA;  the hand-over barrier (tile kt+1 landed, stage cur released) sits in front of step 3's MFMAs;
+    //   the NLD DMA pieces of a tile are spread over step 3 of the previous iteration (right after the hand-over that
+    //   freed their stage) and steps 0 and 1, so the last of them still has ~2 steps of MFMA time to land.
+    constexpr int SG_MFMA = 0x8, SG_VMEM = 0x20, SG_DSR = 0x100;
+    constexpr int NM = TM * TN, NF = TM + TN;
+    constexpr int D3 = (NLD + 2) / 3, D0 = (NLD - D3 + 1) / 2, D1 = NLD - D3 - D0;      // pieces issued in steps 3 / 0 / 1
+    static_assert(NF <= NM, "fewer MFMAs than fragment reads per step");
+    auto issue_range = [&](int stage, int k0, int lo, int hi) {
+        char *base = smem + stage * (ROWS * ROWB);
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            if (u < lo || u >= hi) continue;
+            const int piece = wave + NWAVES * u;
+            const bf16_t *opnd = 8 * piece < BM ? p.A : p.W;
+            glds16h(opnd + (src[u] + (unsigned)k0), base + piece * 1024);
+        }
+    };
     bf16x8 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
     issue(0, 0);
+    issue_range(1, (nk > 1 ? 1 : 0) * BKB, 0, D3);
     __syncthreads();
     load_frags(0, 0, xa0, wb0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const int knext = (kt + 1 < nk ? kt + 1 : nk - 1) * BKB;
-        load_frags(cur, 1, xa1, wb1);
-        issue(cur ^ 1, knext);
-        mfma_step(xa0, wb0);
-        load_frags(cur, 2, xa0, wb0);
-        mfma_step(xa1, wb1);
-        load_frags(cur, 3, xa1, wb1);
+        const int k1 = (kt + 1 < nk ? kt + 1 : nk - 1) * BKB, k2 = (kt + 2 < nk ? kt + 2 : nk - 1) * BKB;
         __builtin_amdgcn_sched_barrier(0);
+        // ---- step 0
+        load_frags(cur, 1, xa1, wb1);
+        issue_range(cur ^ 1, k1, D3, D3 + D0);
         mfma_step(xa0, wb0);
-        __syncthreads();
-        load_frags(cur ^ 1, 0, xa0, wb0);
+#pragma unroll
+        for (int g = 0; g < NF; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < D0; ++g) {
+            if (NF + g < NM) __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 0);
+        }
+        if (NM - NF - D0 > 0) __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF - D0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 1
+        load_frags(cur, 2, xa0, wb0);
+        issue_range(cur ^ 1, k1, D3 + D0, NLD);
         mfma_step(xa1, wb1);
+#pragma unroll
+        for (int g = 0; g < NF; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 1);
+        }
+#pragma unroll
+        for (int g = 0; g < D1; ++g) {
+            if (NF + g < NM) __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 1);
+        }
+        if (NM - NF - D1 > 0) __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF - D1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 2
+        load_frags(cur, 3, xa1, wb1);
+        mfma_step(xa0, wb0);
+#pragma unroll
+        for (int g = 0; g < NF; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 2);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 2);
+        }
+        if (NM - NF > 0) __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- hand-over: own DMA of tile kt+1 landed (vmcnt 0), own reads of stage cur done, then all waves
+        __syncthreads();
+        // ---- step 3: MFMAs of the last fragments | first fragments of tile kt+1 | first DMA pieces of tile kt+2 -> stage cur
+        load_frags(cur ^ 1, 0, xa0, wb0);
+        issue_range(cur, k2, 0, D3);
+        mfma_step(xa1, wb1);
+#pragma unroll
+        for (int g = 0; g < NF; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 3);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, 3);
+        }
+#pragma unroll
+        for (int g = 0; g < D3; ++g) {
+            if (NF + g < NM) __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 3);
+            __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 3);
+        }
+        if (NM - NF - D3 > 0) __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF - D3, 3);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches of the tail must not outlive the LDS allocation
 
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
@@ -246,17 +314,17 @@ int launch_h(const GemmArgsH &a, hipStream_t stream)
 // __syncthreads() would drain the DMA queue), and immediately issues tile kt+3 into the stage every wave has just left.
 // LDS rows are 64 B (32 bf16): one DMA piece = 16 rows, 16-B chunk XOR-swizzled with (row>>2)&3 on the source address
 // and on the read (16 consecutive rows x one chunk -> 16 distinct 16-B slots of the four-row bank line).
-template <int EPI>
-__global__ void __launch_bounds__(512, 2) gemm_bf16_ring(const GemmArgsH p)
+template <int WM, int WN, int TM, int TN, int STAGES, int EPI>
+__global__ void __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) gemm_bf16_ring(const GemmArgsH p)
 {
-    constexpr int BM = 256, BN = 256, ROWS = BM + BN, BK = 32, RB = 64, STAGE_BYTES = ROWS * RB;   // 4 stages
-    constexpr int NW = 8, NLD = ROWS / 16 / NW;          // 4 DMA pieces per wave per k-tile
-    constexpr int TM = 4, TN = 2;                        // wave tile 128 x 64
+    constexpr int NW = WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN, ROWS = BM + BN, BK = 32, RB = 64;
+    constexpr int STAGE_BYTES = ROWS * RB, NLD = ROWS / 16 / NW, DIST = STAGES - 1;
+    static_assert(ROWS % (16 * NW) == 0 && BM % 16 == 0, "DMA pieces (16 rows x 64 B) must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int c32 = lane & 31, h = lane >> 5;
 
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
@@ -305,19 +373,19 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_ring(const GemmArgsH p)
     const int sw = (c32 >> 2) & 3;
     const int a_row = (wm * TM * 32 + c32) * RB, b_row = (BM + wn * TN * 32 + c32) * RB;
 
-    // prologue: tiles 0, 1, 2 in flight (clamped re-fetches when K is shorter; they are harmless and counted)
-    issue(0, 0);
-    issue(1, (nk > 1 ? 1 : nk - 1) * BK);
-    issue(2, (nk > 2 ? 2 : nk - 1) * BK);
+    // prologue: tiles 0 .. DIST-1 in flight (clamped re-fetches when K is shorter; they are harmless and counted)
+#pragma unroll
+    for (int t = 0; t < DIST; ++t) issue(t, (t < nk ? t : nk - 1) * BK);
+    int stage = 0, fill = DIST % STAGES;
     for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed once at most the 2*NLD youngest DMA pieces of this wave are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");
+        // tile kt has landed once at most the (DIST-1)*NLD youngest DMA pieces of this wave are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * NLD) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // stage (kt+3)&3 == (kt-1)&3 was read in the previous iteration; every wave has passed the barrier since.
-        // Past the end the last tile is re-fetched so that the wait above keeps its meaning; drained before the epilogue.
-        issue((kt + 3) & 3, (kt + 3 < nk ? kt + 3 : nk - 1) * BK);
-        const char *st = smem + (kt & 3) * STAGE_BYTES;
+        // the stage filled now was read in the previous iteration; every wave has passed the barrier since.  Past the
+        // end the last tile is re-fetched so that the wait above keeps its meaning; drained before the epilogue.
+        issue(fill, (kt + DIST < nk ? kt + DIST : nk - 1) * BK);
+        const char *st = smem + stage * STAGE_BYTES;
         bf16x8 xa[2][TM], wb[2][TN];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -334,6 +402,8 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_ring(const GemmArgsH p)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[s][j], xa[s][i], acc[i][j], 0, 0, 0);
+        stage = stage + 1 == STAGES ? 0 : stage + 1;
+        fill = fill + 1 == STAGES ? 0 : fill + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail re-fetches must not outlive the LDS allocation
 
@@ -343,19 +413,20 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_ring(const GemmArgsH p)
     else store_h<TM, TN, EPI, true>(p, acc, mw, nw, lane);
 }
 
-template <int EPI>
+template <int WM, int WN, int TM, int TN, int STAGES, int EPI>
 int launch_ring(const GemmArgsH &a, hipStream_t stream)
 {
-    constexpr int lds = 4 * 512 * 64;
-    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-    auto kern = gemm_bf16_ring<EPI>;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int lds = STAGES * (BM + BN) * 64;
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    auto kern = gemm_bf16_ring<WM, WN, TM, TN, STAGES, EPI>;
     static bool attr_set = false;
     if (!attr_set) {
         LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), lds, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }
@@ -478,12 +549,10 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
         if (best < 0 || cost < best) { best = cost; pick = c.id; }
     }
     if (const char *force = getenv("LDIT_GEMM_BF16_TILE")) {
-        if (force[0] >= '0' && force[0] <= '4' && force[1] == 0) pick = force[0] - '0';
+        if (force[0] >= '0' && force[0] <= '5' && force[1] == 0) pick = force[0] - '0';
     }
-    if (pick == 4) {
-        if (a.K % 32) return fail(LDIT_EUNSUPPORTED, "gemm_bf16 ring: K must be a multiple of 32");
-        return launch_ring<EPI>(a, stream);
-    }
+    if (pick == 4) return launch_ring<2, 4, 4, 2, 4, EPI>(a, stream);    // 256 x 256, 8 waves, 4 stages (1 workgroup per CU)
+    if (pick == 5) return launch_ring<2, 2, 4, 2, 3, EPI>(a, stream);    // 256 x 128, 4 waves, 3 stages: 72 KB -> 2 workgroups per CU
     switch (pick) {
         case 3: return launch_h<2, 4, 4, 2, EPI>(a, stream);     // 256 x 256, 8 waves (2 per SIMD)
         case 0: return launch_h<2, 2, 4, 4, EPI>(a, stream);     // 256 x 256, 4 waves
