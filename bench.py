@@ -34,7 +34,7 @@ from layoutdit_amd import config as cfgs, dp, synth           # noqa: E402
 from layoutdit_amd.modeling import DiTEncoder                 # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3    # gfx950 dense fp32 matrix peak (spec; 155 measured), MI355X_MICROARCH.md
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense MFMA peaks (bf16: ~2.5 PF dense, never the 2:1-sparse figure)
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}   # dense MFMA peaks (bf16: ~2.5 PF dense, never the 2:1-sparse figure)
 PER_GPU_BATCH = 64
 
 
@@ -96,8 +96,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="base", choices=sorted(cfgs.GEOMETRIES))
     ap.add_argument("--size", type=int, default=224)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="f32 = BASELINE configs[1] (headline); bf16 with --model large --size 512 --batch 16 = configs[3]")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "fp8"],
+                    help="f32 = BASELINE configs[1] (headline); bf16 with --model large --size 512 --batch 16 = configs[3]; "
+                         "fp8 with --batch 32 = configs[4] (per-GPU share of bs=256 over 8 GPUs)")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU")
     ap.add_argument("--cpu-sample", type=int, default=64, help="images timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-roofline-pass", action="store_true")
@@ -117,6 +118,8 @@ def main() -> None:
     lo, hi = dp.shard_range(args.batch * r.world, r.rank, r.world)       # weak scaling: args.batch images per rank
     x_np = synth.synth_images(hi - lo, args.size, args.size, seed=1234, first_index=lo)
     x = torch.from_numpy(x_np).to(dev)                                    # resident in HBM before the timed region
+    if args.dtype == "fp8":
+        model.calibrate_fp8(x)                                            # per-tensor activation scales, untimed set-up
 
     with torch.no_grad():
         for _ in range(max(args.warmup, 1)):
@@ -171,7 +174,7 @@ def main() -> None:
                                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                                 "traffic": pmc_traffic(args),
                                 "kernel": "fp32 MFMA GEMM family (patch-embed, qkv, o_proj, fc1, fc2)" if args.dtype == "f32"
-                                else "bf16 MFMA GEMM family (qkv, o_proj, fc1, fc2; patch-embed stays fp32)",
+                                else f"{args.dtype} MFMA GEMM family (qkv, o_proj, fc1, fc2; patch-embed stays fp32)",
                                 "launches": n, "avg_launch_ms": round(timing["gemm_ms"] / n, 5),
                                 "flops_per_launch": gemm_flops // n}
             line["kernel_ms_per_step"] = {k[:-3]: round(v / args.steps, 4) for k, v in timing.items() if k.endswith("_ms")}

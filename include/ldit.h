@@ -39,7 +39,20 @@ enum ldit_status {
 
 enum ldit_dtype {
     LDIT_F32 = 0,  /* everything fp32 (exact-fp32 MFMA) */
-    LDIT_BF16 = 1  /* GEMM / attention operands bf16, fp32 accumulation, residual stream / LayerNorm / softmax fp32; taps fp32 */
+    LDIT_BF16 = 1, /* GEMM / attention operands bf16, fp32 accumulation, residual stream / LayerNorm / softmax fp32; taps fp32 */
+    LDIT_FP8 = 3   /* BASELINE.json configs[4]: the four GEMMs of a layer on fp8 e4m3 (OCP) operands with per-tensor scales,
+                      fp32 accumulation; attention on bf16 q|k|v; residual stream / LayerNorm / softmax fp32; taps fp32.
+                      Weight scales are measured by ldit_pack_weights; the four activation scales per layer come from
+                      ldit_set_fp8_act_scales (calibration is the caller's job) */
+};
+
+/* order of the per-layer activation scales handed to ldit_set_fp8_act_scales (scale = amax / 448) */
+enum ldit_fp8_act {
+    LDIT_FP8_A_LN1 = 0,   /* layernorm_before output -> q|k|v GEMM */
+    LDIT_FP8_A_ATTN = 1,  /* attention output        -> o_proj GEMM */
+    LDIT_FP8_A_LN2 = 2,   /* layernorm_after output  -> fc1 GEMM */
+    LDIT_FP8_A_GELU = 3,  /* gelu(fc1) output        -> fc2 GEMM */
+    LDIT_FP8_A_COUNT = 4
 };
 
 /* epilogues of ldit_linear_f32 (what is fused behind the matmul) */
@@ -105,6 +118,11 @@ size_t ldit_packed_bytes(const ldit_cfg *cfg);
 /* Gather the caller's parameter tensors into `packed` (device), fusing q/k/v into one [3C,C] matrix with bias
  * [bq ; 0 ; bv] (the key projection has no bias, TF:306).  Call again whenever parameters change. */
 int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, size_t packed_bytes, ldit_stream stream);
+
+/* LDIT_FP8 only: store the activation scales (HOST array, layers x LDIT_FP8_A_COUNT floats, all > 0) into `packed`.
+ * Until this has been called after ldit_pack_weights the fp8 forward's output is undefined (scales are zero). */
+int ldit_set_fp8_act_scales(const ldit_cfg *cfg, void *packed, size_t packed_bytes, const float *act_scales,
+                            ldit_stream stream);
 
 /* Scratch bytes ldit_vit_forward needs for a batch of `batch` images. */
 size_t ldit_workspace_bytes(const ldit_cfg *cfg, int32_t batch);
@@ -172,6 +190,25 @@ int ldit_attention_bf16(const void *Q, const void *K, const void *V, void *O, in
 
 /* dst[i] = bf16(src[i]) (round to nearest even), n elements. */
 int ldit_cast_f32_bf16(const void *src, void *dst, int64_t n, ldit_stream stream);
+
+/* ---- fp8 (OCP e4m3) building blocks: groundwork for BASELINE.json configs[4] (fp8 forward) ---------------------------
+ * Per-tensor symmetric scaling: a tensor T is held as fp8 codes q with T ~= scale_T * q, scale_T = amax(T) / 448.
+ *
+ * ldit_linear_fp8:  Y = epilogue(ab_scale * (X8 . W8^T) + bias)  with X8 [M,K] (row stride lda BYTES = elements) and
+ * W8 [N,K] fp8 e4m3, fp32 accumulation (v_mfma_f32_32x32x16_fp8_fp8), ab_scale = scale_X * scale_W.  K % 128 == 0,
+ * lda % 16 == 0.  bias / lam fp32.  LDIT_EPI_BIAS writes bf16 Y; LDIT_EPI_BIAS_GELU writes fp8 Y =
+ * sat(gelu(.) * out_inv_scale) (ldy in elements); LDIT_EPI_SCALE_RESID reads the fp32 residual R (may alias Y),
+ * writes fp32 Y and the optional fp32 copy Y2. */
+int ldit_linear_fp8(const void *X, int64_t lda, const void *W, const void *bias, void *Y, int64_t ldy, int64_t M, int64_t N,
+                    int64_t K, int32_t epilogue, const void *lam, const void *R, void *Y2, float ab_scale,
+                    float out_inv_scale, ldit_stream stream);
+
+/* dst[i] = fp8_e4m3(src[i] * inv_scale), round to nearest even, SATURATING at +-448 (torch's cast yields NaN above
+ * 464 instead); n elements, src 16-byte aligned, dst 4-byte aligned. */
+int ldit_quant_f32_fp8(const void *src, void *dst, int64_t n, float inv_scale, ldit_stream stream);
+
+/* *out (one device float) = max |src[i]|, i < n (0 for n == 0).  Enqueues a 4-byte memset + one kernel. */
+int ldit_amax_f32(const void *src, int64_t n, void *out, ldit_stream stream);
 
 /* Detector input transform (the step that produces `x`; ref src/layoutdit/modeling/model.py:50-54 configures
  * torchvision's GeneralizedRCNNTransform with fixed_size = (224, 224), image_mean = image_std = 0.5): for each image

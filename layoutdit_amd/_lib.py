@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libldit_hip.so")
 
 LDIT_ABI_VERSION = 1
 LDIT_MAX_TAPS = 8
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_FP8 = 0, 1, 3
+FP8_A_COUNT = 4
 LDIT_OK, LDIT_EINVAL, LDIT_EWORKSPACE, LDIT_EHIP, LDIT_EUNSUPPORTED = 0, -1, -2, -3, -4
 EPI_BIAS, EPI_BIAS_GELU, EPI_SCALE_RESID = 0, 1, 2
 K_GEMM, K_ATTENTION, K_LAYERNORM, K_OTHER, K_COUNT = 0, 1, 2, 3, 4
@@ -59,6 +60,10 @@ SIGNATURES = {
     "ldit_linear_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "ldit_attention_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ldit_cast_f32_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "ldit_linear_fp8": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _f32, _f32, _vp]),
+    "ldit_set_fp8_act_scales": (C.c_int, [C.POINTER(LditCfg), _vp, C.c_size_t, C.POINTER(C.c_float), _vp]),
+    "ldit_quant_f32_fp8": (C.c_int, [_vp, _vp, _i64, _f32, _vp]),
+    "ldit_amax_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "ldit_preprocess_f32": (C.c_int, [C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i32), _i32, _i32, _f32, _f32, _i32, _i32,
                                       _vp, _vp]),
 }

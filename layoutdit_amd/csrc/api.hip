@@ -1,6 +1,9 @@
 // C-ABI entry points of libldit_hip.so (declared in include/ldit.h).  Host-side sequencing only: every byte of
 // arithmetic happens in the HIP kernels of this directory; there is no CPU fallback.
+#include <cmath>
 #include <cstring>
+#include <initializer_list>
+#include <utility>
 #include <vector>
 
 #include "ldit_common.h"
@@ -33,8 +36,8 @@ struct Geo {
 int geometry(const ldit_cfg *cfg, Geo &g)
 {
     if (!cfg) return fail(LDIT_EINVAL, "cfg is null");
-    if (cfg->dtype != LDIT_F32 && cfg->dtype != LDIT_BF16)
-        return fail(LDIT_EUNSUPPORTED, "dtype %d: only fp32 (0) and bf16 (1) are implemented", cfg->dtype);
+    if (cfg->dtype != LDIT_F32 && cfg->dtype != LDIT_BF16 && cfg->dtype != LDIT_FP8)
+        return fail(LDIT_EUNSUPPORTED, "dtype %d: only fp32 (0), bf16 (1) and fp8 e4m3 (3) are implemented", cfg->dtype);
     g.C = cfg->hidden; g.L = cfg->layers; g.H = cfg->heads; g.F = cfg->mlp; g.p = cfg->patch; g.in_ch = cfg->in_ch;
     if (g.C <= 0 || g.L < 0 || g.H <= 0 || g.F <= 0 || g.p <= 0 || g.in_ch <= 0) return fail(LDIT_EINVAL, "cfg: non-positive dimension");
     if (g.C % g.H) return fail(LDIT_EINVAL, "cfg: hidden %d not divisible by heads %d", g.C, g.H);
@@ -42,6 +45,7 @@ int geometry(const ldit_cfg *cfg, Geo &g)
     if (g.D != 64) return fail(LDIT_EUNSUPPORTED, "cfg: head_dim %d, only 64 is implemented", g.D);
     if (g.C % 32 || g.F % 32) return fail(LDIT_EUNSUPPORTED, "cfg: hidden and mlp must be multiples of 32");
     if (cfg->dtype == LDIT_BF16 && (g.C % 64 || g.F % 64)) return fail(LDIT_EUNSUPPORTED, "cfg: bf16 needs hidden and mlp multiples of 64");
+    if (cfg->dtype == LDIT_FP8 && (g.C % 128 || g.F % 128)) return fail(LDIT_EUNSUPPORTED, "cfg: fp8 needs hidden and mlp multiples of 128");
     if (cfg->img_h <= 0 || cfg->img_w <= 0 || cfg->img_h % g.p || cfg->img_w % g.p)
         return fail(LDIT_EINVAL, "cfg: image %dx%d is not a multiple of patch %d", cfg->img_h, cfg->img_w, g.p);
     g.gh = cfg->img_h / g.p; g.gw = cfg->img_w / g.p; g.P = g.gh * g.gw; g.T = g.P + 1;
@@ -54,8 +58,10 @@ int geometry(const ldit_cfg *cfg, Geo &g)
 }
 
 // Byte offsets into the packed parameter block; every offset is a multiple of 16 bytes.  In the bf16 build the four
-// big matrices of a layer (fused q|k|v, o_proj, fc1, fc2) are stored as bf16; everything else stays fp32.
-struct PackedLayer { size_t ln1_w, ln1_b, wqkv, bqkv, wo, bo, lam1, ln2_w, ln2_b, w1, b1, w2, b2, lam2; };
+// big matrices of a layer (fused q|k|v, o_proj, fc1, fc2) are stored as bf16, in the fp8 build as e4m3 codes; everything
+// else stays fp32.  fp8 adds 8 floats of scales per layer, ordered so that each GEMM finds {activation scale, weight
+// scale} adjacent: [a_ln1, w_qkv, a_attn, w_o, a_ln2, w_fc1, a_gelu, w_fc2].
+struct PackedLayer { size_t ln1_w, ln1_b, wqkv, bqkv, wo, bo, lam1, ln2_w, ln2_b, w1, b1, w2, b2, lam2, scales; };
 struct PackedMap {
     size_t patch_w, patch_b, cls, pos, total;
     std::vector<PackedLayer> layer;
@@ -65,7 +71,7 @@ PackedMap packed_map(const Geo &g, int dtype)
 {
     PackedMap m;
     size_t o = 0;
-    const size_t mat = dtype == LDIT_BF16 ? 2 : 4;
+    const size_t mat = dtype == LDIT_FP8 ? 1 : dtype == LDIT_BF16 ? 2 : 4;
     auto take = [&](size_t n, size_t elt) { size_t at = o; o += up(n * elt, 16); return at; };
     m.patch_w = take((size_t)g.C * g.Kp, 4);
     m.patch_b = take(g.C, 4);
@@ -80,6 +86,7 @@ PackedMap packed_map(const Geo &g, int dtype)
         pl.ln2_w = take(g.C, 4); pl.ln2_b = take(g.C, 4);
         pl.w1 = take((size_t)g.F * g.C, mat); pl.b1 = take(g.F, 4);
         pl.w2 = take((size_t)g.C * g.F, mat); pl.b2 = take(g.C, 4); pl.lam2 = take(g.C, 4);
+        pl.scales = dtype == LDIT_FP8 ? take(8, 4) : 0;
     }
     m.total = o;
     return m;
@@ -91,7 +98,7 @@ Workspace workspace_map(const Geo &g, int batch, int dtype)
 {
     const size_t M = (size_t)batch * g.T;
     const size_t wide = (size_t)(3 * g.C > g.F ? 3 * g.C : g.F);
-    const size_t act = dtype == LDIT_BF16 ? 2 : 4;
+    const size_t act = dtype == LDIT_F32 ? 4 : 2;   // fp8 build: sized for its bf16 q|k|v; the fp8 buffers need less
     Workspace w;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += up(bytes, 256); return at; };
@@ -224,11 +231,29 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
     }
 
     const float scale = 1.0f / sqrtf((float)g.D);
-    const bool bf16 = cfg->dtype == LDIT_BF16;
+    const bool bf16 = cfg->dtype == LDIT_BF16, fp8 = cfg->dtype == LDIT_FP8;
     for (int l = 0; l < g.L; ++l) {
         const PackedLayer &pl = pm.layer[l];
         float *tap = tap_for(l + 1);
-        if (!bf16) {
+        if (fp8) {
+            // fp8 build: LayerNorm, the attention epilogue and the GELU epilogue quantise straight to e4m3 with the
+            // calibrated per-tensor scales; q|k|v leave their GEMM as bf16 for the bf16 attention kernel.
+            char *y8 = ws + wm.y, *bb = ws + wm.big;
+            const float *sc = F32(pl.scales);
+            LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_fp8out(h, F32(pl.ln1_w), F32(pl.ln1_b), y8, M, C, cfg->ln_eps, sc + 0, stream));
+            LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_fp8(y8, C, P + pl.wqkv, F32(pl.bqkv), bb, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr,
+                                                        nullptr, nullptr, 0.f, 0.f, sc + 0, nullptr, stream));
+            LDIT_RUN(probe, LDIT_K_ATTENTION,
+                     launch_attention_bf16_fp8out(bb, bb + 2 * (size_t)C, bb + 4 * (size_t)C, y8, batch, g.T, g.H, g.D, 3 * C, 3 * C,
+                                                  3 * C, C, scale, sc + 2, stream));
+            LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_fp8(y8, C, P + pl.wo, F32(pl.bo), h, C, M, C, C, EPI_SCALE_RESID, F32(pl.lam1), h,
+                                                        nullptr, 0.f, 0.f, sc + 2, nullptr, stream));
+            LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_fp8out(h, F32(pl.ln2_w), F32(pl.ln2_b), y8, M, C, cfg->ln_eps, sc + 4, stream));
+            LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_fp8(y8, C, P + pl.w1, F32(pl.b1), bb, F, M, F, C, EPI_BIAS_GELU, nullptr, nullptr,
+                                                        nullptr, 0.f, 0.f, sc + 4, sc + 6, stream));
+            LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_fp8(bb, F, P + pl.w2, F32(pl.b2), h, C, M, C, F, EPI_SCALE_RESID, F32(pl.lam2), h,
+                                                        tap, 0.f, 0.f, sc + 6, nullptr, stream));
+        } else if (!bf16) {
             // y = LN1(h)                                                               TF:426
             LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm(h, F32(pl.ln1_w), F32(pl.ln1_b), y, M, C, cfg->ln_eps, stream));
             // big[:, 0:3C] = y . [Wq;Wk;Wv]^T + [bq;0;bv]                               TF:319-321
@@ -296,7 +321,8 @@ int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, 
     if (packed_bytes < pm.total) return fail(LDIT_EWORKSPACE, "packed buffer %zu bytes < required %zu", packed_bytes, pm.total);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     char *P = static_cast<char *>(packed);
-    const bool bf16 = cfg->dtype == LDIT_BF16;
+    const bool bf16 = cfg->dtype == LDIT_BF16, fp8 = cfg->dtype == LDIT_FP8;
+    float *cur_scale = nullptr;
     auto put = [&](size_t off, const void *src, size_t n, const char *what) -> int {      // fp32 copy
         if (!src) return fail(LDIT_EINVAL, "weights: %s is null", what);
         LDIT_HIP_CHECK(hipMemcpyAsync(P + off, src, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -304,9 +330,22 @@ int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, 
     };
     auto put_mat = [&](size_t off, size_t elt_off, const void *src, size_t n, const char *what) -> int {   // matrix: fp32 or -> bf16
         if (!src) return fail(LDIT_EINVAL, "weights: %s is null", what);
-        if (!bf16) return put(off + elt_off * 4, src, n, what);
+        if (!bf16 && !fp8) return put(off + elt_off * 4, src, n, what);
         if (!aligned16(src)) return fail(LDIT_EINVAL, "weights: %s must be 16-byte aligned", what);
+        if (fp8) return launch_quant_fp8(static_cast<const float *>(src), P + off + elt_off, n, 0.f, cur_scale, stream);
         return launch_cvt_bf16(static_cast<const float *>(src), P + off + elt_off * 2, n, stream);
+    };
+    // fp8: measure the per-tensor weight scale (amax / 448) of up to three source tensors into the layer's scale slot
+    auto measure = [&](size_t scales_off, int slot, std::initializer_list<std::pair<const void *, size_t>> parts) -> int {
+        if (!fp8) return LDIT_OK;
+        cur_scale = reinterpret_cast<float *>(P + scales_off) + slot;
+        bool first = true;
+        for (const auto &pr : parts) {
+            if (!pr.first) return fail(LDIT_EINVAL, "weights: null matrix");
+            LDIT_TRY(launch_amax_f32(static_cast<const float *>(pr.first), pr.second, cur_scale, !first, stream));
+            first = false;
+        }
+        return launch_amax_to_scale(cur_scale, 1, stream);
     };
     const size_t C = g.C, F = g.F;
     LDIT_TRY(put(pm.patch_w, w->patch_w, C * g.Kp, "patch_w"));
@@ -318,23 +357,49 @@ int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, 
         const PackedLayer &pl = pm.layer[l];
         LDIT_TRY(put(pl.ln1_w, s.ln1_w, C, "ln1_w"));
         LDIT_TRY(put(pl.ln1_b, s.ln1_b, C, "ln1_b"));
+        if (fp8) LDIT_HIP_CHECK(hipMemsetAsync(P + pl.scales, 0, 8 * sizeof(float), stream));
+        LDIT_TRY(measure(pl.scales, 1, {{s.wq, C * C}, {s.wk, C * C}, {s.wv, C * C}}));
         LDIT_TRY(put_mat(pl.wqkv, 0, s.wq, C * C, "wq"));
         LDIT_TRY(put_mat(pl.wqkv, C * C, s.wk, C * C, "wk"));
         LDIT_TRY(put_mat(pl.wqkv, 2 * C * C, s.wv, C * C, "wv"));
         if (!s.bq || !s.bv) return fail(LDIT_EINVAL, "weights: bq / bv is null");
         LDIT_TRY(launch_pack_qkv_bias(static_cast<const float *>(s.bq), static_cast<const float *>(s.bv),
                                       reinterpret_cast<float *>(P + pl.bqkv), g.C, stream));
+        LDIT_TRY(measure(pl.scales, 3, {{s.wo, C * C}}));
         LDIT_TRY(put_mat(pl.wo, 0, s.wo, C * C, "wo"));
         LDIT_TRY(put(pl.bo, s.bo, C, "bo"));
         LDIT_TRY(put(pl.lam1, s.lam1, C, "lam1"));
         LDIT_TRY(put(pl.ln2_w, s.ln2_w, C, "ln2_w"));
         LDIT_TRY(put(pl.ln2_b, s.ln2_b, C, "ln2_b"));
+        LDIT_TRY(measure(pl.scales, 5, {{s.w1, F * C}}));
         LDIT_TRY(put_mat(pl.w1, 0, s.w1, F * C, "w1"));
         LDIT_TRY(put(pl.b1, s.b1, F, "b1"));
+        LDIT_TRY(measure(pl.scales, 7, {{s.w2, C * F}}));
         LDIT_TRY(put_mat(pl.w2, 0, s.w2, C * F, "w2"));
         LDIT_TRY(put(pl.b2, s.b2, C, "b2"));
         LDIT_TRY(put(pl.lam2, s.lam2, C, "lam2"));
     }
+    return LDIT_OK;
+}
+
+int ldit_set_fp8_act_scales(const ldit_cfg *cfg, void *packed, size_t packed_bytes, const float *act_scales, ldit_stream stream_)
+{
+    Geo g;
+    LDIT_TRY(geometry(cfg, g));
+    if (cfg->dtype != LDIT_FP8) return fail(LDIT_EINVAL, "set_fp8_act_scales: cfg.dtype is not LDIT_FP8");
+    if (!packed || !act_scales) return fail(LDIT_EINVAL, "set_fp8_act_scales: null pointer");
+    const PackedMap pm = packed_map(g, cfg->dtype);
+    if (packed_bytes < pm.total) return fail(LDIT_EWORKSPACE, "packed buffer %zu bytes < required %zu", packed_bytes, pm.total);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char *P = static_cast<char *>(packed);
+    for (int l = 0; l < g.L; ++l)
+        for (int a = 0; a < LDIT_FP8_A_COUNT; ++a) {
+            const float v = act_scales[l * LDIT_FP8_A_COUNT + a];
+            if (!(v > 0.0f) || !std::isfinite(v)) return fail(LDIT_EINVAL, "set_fp8_act_scales: layer %d scale %d = %g is not positive", l, a, (double)v);
+            // slots 0, 2, 4, 6 of the layer's scale block; 4-byte pageable copies complete before the call returns
+            LDIT_HIP_CHECK(hipMemcpyAsync(P + pm.layer[l].scales + 8 * a, &act_scales[l * LDIT_FP8_A_COUNT + a], sizeof(float),
+                                          hipMemcpyHostToDevice, stream));
+        }
     return LDIT_OK;
 }
 
@@ -455,6 +520,35 @@ int ldit_cast_f32_bf16(const void *src, void *dst, int64_t n, ldit_stream stream
     if (n < 0 || (n && (!src || !dst))) return fail(LDIT_EINVAL, "cast: null operand");
     if (!aligned16(src) || (reinterpret_cast<uintptr_t>(dst) & 7u)) return fail(LDIT_EINVAL, "cast: misaligned operand");
     return launch_cvt_bf16(static_cast<const float *>(src), dst, (size_t)n, static_cast<hipStream_t>(stream));
+}
+
+int ldit_linear_fp8(const void *X, int64_t lda, const void *W, const void *bias, void *Y, int64_t ldy, int64_t M, int64_t N,
+                    int64_t K, int32_t epilogue, const void *lam, const void *R, void *Y2, float ab_scale, float out_inv_scale,
+                    ldit_stream stream)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return fail(LDIT_EINVAL, "linear_fp8: empty problem");
+    if (M * (ldy > lda ? ldy : lda) >= (1ll << 31) || N * K >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "linear_fp8: operand exceeds 2^31 elements");
+    if (ldy < N || lda < K) return fail(LDIT_EINVAL, "linear_fp8: bad leading dimension");
+    if (!Y || (reinterpret_cast<uintptr_t>(Y) & 15u) || (Y2 && !aligned16(Y2))) return fail(LDIT_EINVAL, "linear_fp8: output null or misaligned");
+    if (epilogue < LDIT_EPI_BIAS || epilogue > LDIT_EPI_SCALE_RESID) return fail(LDIT_EINVAL, "linear_fp8: unknown epilogue %d", epilogue);
+    if (!(ab_scale > 0.0f) || (epilogue == LDIT_EPI_BIAS_GELU && !(out_inv_scale > 0.0f))) return fail(LDIT_EINVAL, "linear_fp8: scales must be positive");
+    return launch_gemm_fp8(X, (int)lda, W, static_cast<const float *>(bias), Y, (int)ldy, (int)M, (int)N, (int)K, epilogue,
+                           static_cast<const float *>(lam), static_cast<const float *>(R), static_cast<float *>(Y2), ab_scale,
+                           out_inv_scale, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int ldit_quant_f32_fp8(const void *src, void *dst, int64_t n, float inv_scale, ldit_stream stream)
+{
+    if (n < 0 || (n && (!src || !dst))) return fail(LDIT_EINVAL, "quant_fp8: null operand");
+    if (!aligned16(src) || (reinterpret_cast<uintptr_t>(dst) & 3u)) return fail(LDIT_EINVAL, "quant_fp8: misaligned operand");
+    if (!(inv_scale > 0.0f)) return fail(LDIT_EINVAL, "quant_fp8: inv_scale must be positive");
+    return launch_quant_fp8(static_cast<const float *>(src), dst, (size_t)n, inv_scale, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int ldit_amax_f32(const void *src, int64_t n, void *out, ldit_stream stream)
+{
+    if (n < 0 || !out || (n && !src)) return fail(LDIT_EINVAL, "amax: null operand");
+    return launch_amax_f32(static_cast<const float *>(src), (size_t)n, static_cast<float *>(out), false, static_cast<hipStream_t>(stream));
 }
 
 int ldit_preprocess_f32(const void *const *images, const int32_t *heights, const int32_t *widths, int32_t B, int32_t in_ch,

@@ -23,11 +23,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int KROWB = 128;            // bytes per K row in LDS (64 bf16), chunk-swizzled like the GEMM tiles
 constexpr int VPAD = 8;               // bf16 of padding per V^T row: 528-B stride -> conflict-free b128 reads over d
 
-template <int KT, int NW>
+// OUT_FP8: O is written as fp8 e4m3 codes of o / *qscale (operand of the fp8 o_proj GEMM), ldo in elements.
+template <int KT, int NW, bool OUT_FP8>
 __global__ void __launch_bounds__(NW * 64, NW / 4) attention_bf16(const bf16_t *__restrict__ Q, const bf16_t *__restrict__ K,
-                                                                  const bf16_t *__restrict__ V, bf16_t *__restrict__ O,
+                                                                  const bf16_t *__restrict__ V, void *__restrict__ Ov,
                                                                   int N, int H, int ldq, int ldk, int ldv, int ldo,
-                                                                  float scale, int nqg)
+                                                                  float scale, int nqg, const float *__restrict__ qscale)
 {
     constexpr int KC = KT * 32, VSTR = KC + VPAD;     // keys per chunk; V^T row stride in bf16
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -154,10 +155,20 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attention_bf16(const bf16_t *
 
     if (!active) return;
     const float l = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l;
+    const float inv = OUT_FP8 ? 1.0f / (l * qscale[0]) : 1.0f / l;
     const int qrow = qt * 32 + c32;
-    if (qrow < N) {
-        bf16_t *op = O + (tok0 + qrow) * ldo + head * 64 + 4 * h;
+    if (OUT_FP8) {
+        if (qrow < N) {
+            unsigned char *op = static_cast<unsigned char *>(Ov) + (tok0 + qrow) * ldo + head * 64 + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<unsigned *>(op + dt * 32 + 8 * g) =
+                        pack_fp8x4(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        }
+    } else if (qrow < N) {
+        bf16_t *op = static_cast<bf16_t *>(Ov) + (tok0 + qrow) * ldo + head * 64 + 4 * h;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -171,19 +182,20 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attention_bf16(const bf16_t *
 
 }  // namespace
 
-int launch_attention_bf16(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ldq, int ldk,
-                          int ldv, int ldo, float scale, hipStream_t stream)
+template <bool OUT_FP8>
+static int launch_attn(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ldq, int ldk, int ldv,
+                       int ldo, float scale, const float *qscale, hipStream_t stream)
 {
     if (B <= 0 || N <= 0 || H <= 0) return fail(LDIT_EINVAL, "attention_bf16: empty problem");
     if (D != 64) return fail(LDIT_EUNSUPPORTED, "attention_bf16: head_dim=%d, only 64 is implemented", D);
     if (!Q || !K || !V || !O) return fail(LDIT_EINVAL, "attention_bf16: null operand");
     if ((ldq | ldk | ldv) & 7 || (ldo & 3)) return fail(LDIT_EINVAL, "attention_bf16: row strides must be multiples of 8 (in) / 4 (out)");
-    if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || (reinterpret_cast<uintptr_t>(O) & 7u))
+    if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || (reinterpret_cast<uintptr_t>(O) & (OUT_FP8 ? 3u : 7u)))
         return fail(LDIT_EINVAL, "attention_bf16: operands must be 16-byte aligned");
     constexpr int KT = 8, NW = 8;
     constexpr int lds = KT * 32 * KROWB + 64 * (KT * 32 + VPAD) * 2;
     const int nqt = (N + 31) / 32, nqg = (nqt + NW - 1) / NW;
-    auto kern = attention_bf16<KT, NW>;
+    auto kern = attention_bf16<KT, NW, OUT_FP8>;
     static bool attr_set = false;
     if (!attr_set) {
         LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -191,10 +203,23 @@ int launch_attention_bf16(const void *Q, const void *K, const void *V, void *O, 
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(B * H * nqg)), dim3(NW * 64), lds, stream, static_cast<const bf16_t *>(Q),
-                       static_cast<const bf16_t *>(K), static_cast<const bf16_t *>(V), static_cast<bf16_t *>(O), N, H, ldq,
-                       ldk, ldv, ldo, scale, nqg);
+                       static_cast<const bf16_t *>(K), static_cast<const bf16_t *>(V), O, N, H, ldq, ldk, ldv, ldo, scale, nqg,
+                       qscale);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
+}
+
+int launch_attention_bf16(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ldq, int ldk,
+                          int ldv, int ldo, float scale, hipStream_t stream)
+{
+    return launch_attn<false>(Q, K, V, O, B, N, H, D, ldq, ldk, ldv, ldo, scale, nullptr, stream);
+}
+
+int launch_attention_bf16_fp8out(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ldq,
+                                 int ldk, int ldv, int ldo, float scale, const float *qscale, hipStream_t stream)
+{
+    if (!qscale) return fail(LDIT_EINVAL, "attention_bf16: fp8 output needs a scale");
+    return launch_attn<true>(Q, K, V, O, B, N, H, D, ldq, ldk, ldv, ldo, scale, qscale, stream);
 }
 
 }  // namespace ldit

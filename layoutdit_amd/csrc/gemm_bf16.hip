@@ -431,6 +431,145 @@ int launch_ring(const GemmArgsH &a, hipStream_t stream)
     return LDIT_OK;
 }
 
+// ---- ping-pong kernel: 256 x 256 tile, 8 waves (2 x 4), BK = 32, four LDS stages, the two waves of a SIMD alternate --------
+// Free-running, the two waves that share a SIMD want the MFMA pipe at the same time and the LDS at the same time.  Here
+// they are forced out of phase: every wave's k-step is  [LOAD: 12 fragment reads of tile i] barrier [MATH: 16 MFMAs of
+// tile i] barrier,  and the wm = 1 half of the workgroup runs one barrier behind the wm = 0 half (wave w and w + 4 share
+// SIMD w % 4), so in every barrier-to-barrier slot one wave per SIMD streams MFMAs at raised priority while the other
+// refills its fragments and feeds the DMA ring.
+//   slots:    G0 tile i: LOAD 2i, MATH 2i+1        G1 tile i: LOAD 2i+1, MATH 2i+2
+//   WAR:  tile i+3 (stage of tile i-1) is issued at the head of MATH(i): G1's reads of tile i-1 (slot 2i-1) were retired by
+//         its lgkmcnt(0) in slot 2i, and every wave has passed barrier 2i+1 since.
+//   RAW:  every wave waits (counted vmcnt: only tile i+2 may still fly) for ITS pieces of tile i+1 at the end of LOAD(i),
+//         i.e. before barrier 2i+2; the first read of tile i+1 is G0's in slot 2i+2.
+template <int EPI>
+__global__ void __launch_bounds__(512, 2) gemm_bf16_pp(const GemmArgsH p)
+{
+    constexpr int WN = 4, TM = 4, TN = 2, NW = 8, BM = 256, BN = 256, ROWS = BM + BN, BK = 32, RB = 64, STAGES = 4;
+    constexpr int STAGE_BYTES = ROWS * RB, NLD = ROWS / 16 / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int c32 = lane & 31, h = lane >> 5;
+
+    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+    const int ntiles = nbm * nbn;
+    int tile;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = ntiles >> 3, rr = ntiles & 7;
+        tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+
+    unsigned src[NLD];   // bf16 element offsets
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int piece = wave + NW * u, row = 16 * piece + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        if (16 * piece < BM) {
+            int gm = m0 + row;
+            gm = gm < p.M ? gm : p.M - 1;
+            src[u] = (unsigned)gm * (unsigned)p.lda + c * 8;
+        } else {
+            int gn = n0 + row - BM;
+            gn = gn < p.N ? gn : p.N - 1;
+            src[u] = (unsigned)gn * (unsigned)p.K + c * 8;
+        }
+    }
+    auto issue = [&](int stage, int k0) {
+        char *base = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int piece = wave + NW * u;
+            const bf16_t *opnd = 16 * piece < BM ? p.A : p.W;
+            glds16h(opnd + (src[u] + (unsigned)k0), base + piece * 1024);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = p.K / BK;
+    const int sw = (c32 >> 2) & 3;
+    const int a_row = (wm * TM * 32 + c32) * RB, b_row = (BM + wn * TN * 32 + c32) * RB;
+
+    // prologue: tiles 0, 1, 2 in flight (clamped re-fetches when K is shorter: harmless, and they keep the counts valid)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) issue(t, (t < nk ? t : nk - 1) * BK);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile 0
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                       // the stagger: G1 runs one slot behind G0
+    __builtin_amdgcn_sched_barrier(0);
+
+    int stage = 0, fill = 3;
+    for (int kt = 0; kt < nk; ++kt) {
+        // ---- LOAD slot -----------------------------------------------------------------------------------------------
+        const char *st = smem + stage * STAGE_BYTES;
+        bf16x8 xa[2][TM], wb[2][TN];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const char *base = st + (((2 * s + h) ^ sw) * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wb[s][j] = *reinterpret_cast<const bf16x8 *>(base + b_row + j * 32 * RB);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xa[s][i] = *reinterpret_cast<const bf16x8 *>(base + a_row + i * 32 * RB);
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");    // this wave's pieces of tile kt+1 have landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MATH slot -----------------------------------------------------------------------------------------------
+        issue(fill, (kt + 3 < nk ? kt + 3 : nk - 1) * BK);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[s][j], xa[s][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        stage = (stage + 1) & (STAGES - 1);
+        fill = (fill + 1) & (STAGES - 1);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                       // pairs with G1's extra barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail re-fetches must not outlive the LDS allocation
+
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
+    const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
+    if (interior) store_h<TM, TN, EPI, false>(p, acc, mw, nw, lane);
+    else store_h<TM, TN, EPI, true>(p, acc, mw, nw, lane);
+}
+
+template <int EPI>
+int launch_pp(const GemmArgsH &a, hipStream_t stream)
+{
+    constexpr int lds = 4 * 512 * 64;
+    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    auto kern = gemm_bf16_pp<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, stream, a);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
 // ---- skinny kernel: up to 64 rows (the ragged tail peeled off by launch_gemm_bf16) -----------------------------------
 // A 16-row remainder on a 128 x 128 tile is a serial K loop of ~0.4 us per k-tile (24 us at K = 4096) with 8 workgroups
 // on the machine.  Here a workgroup owns 64 rows x 64 columns and its EIGHT waves split K: every wave multiplies the
@@ -549,8 +688,9 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
         if (best < 0 || cost < best) { best = cost; pick = c.id; }
     }
     if (const char *force = getenv("LDIT_GEMM_BF16_TILE")) {
-        if (force[0] >= '0' && force[0] <= '5' && force[1] == 0) pick = force[0] - '0';
+        if (force[0] >= '0' && force[0] <= '6' && force[1] == 0) pick = force[0] - '0';
     }
+    if (pick == 6) return launch_pp<EPI>(a, stream);                      // 256 x 256 ping-pong
     if (pick == 4) return launch_ring<2, 4, 4, 2, 4, EPI>(a, stream);    // 256 x 256, 8 waves, 4 stages (1 workgroup per CU)
     if (pick == 5) return launch_ring<2, 2, 4, 2, 3, EPI>(a, stream);    // 256 x 128, 4 waves, 3 stages: 72 KB -> 2 workgroups per CU
     switch (pick) {
@@ -586,7 +726,8 @@ int launch_gemm_bf16(const void *A, int lda, const void *W, const float *bias, v
                      const float *lam, const float *R, float *Y2, hipStream_t stream)
 {
     const int rem = M % 256;
-    if (M >= 1024 && rem != 0 && rem <= 64 && !getenv("LDIT_GEMM_BF16_TILE")) {
+    const long nbn = (N + 255) / 256, full = ((long)M / 256 + 1) * nbn, mainp = ((long)M / 256) * nbn;
+    if (rem != 0 && rem <= 64 && M > 256 && (full + 255) / 256 > (mainp + 255) / 256) {   // peel only when it saves a round
         const int main_rows = M - rem;
         const size_t out_elt = epi == EPI_SCALE_RESID ? 4 : 2;
         int rc = launch_gemm_bf16_one(A, lda, W, bias, Y, ldy, main_rows, N, K, epi, lam, R, Y2, stream);

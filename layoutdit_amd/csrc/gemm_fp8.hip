@@ -1,0 +1,526 @@
+// fp8 (OCP e4m3, gfx950) MFMA GEMM with per-tensor scales:  Y[M,N] = epi( sa*sw * (A8[M,K] . W8[N,K]^T) ),
+// A8, W8 fp8 e4m3 (K-contiguous), fp32 accumulate.  Groundwork for BASELINE configs[4] (fp8 forward).
+//
+// Same skeleton as gemm_bf16.hip: K-contiguous operands -> LDS by LDS-DMA, 128-B LDS rows (128 fp8), 16-B chunk
+// XOR-swizzled with (row>>1)&7, two stages, 2 x 4 waves (two per SIMD) on a 256 x 256 tile.  A lane's b128 fragment read
+// holds 16 consecutive fp8 of its row: the low 8 bytes feed one v_mfma_f32_32x32x16_fp8_fp8, the high 8 bytes the next
+// (a permutation of the k order applied identically to both operands), so each LDS read pays for two MFMAs.
+// The non-scaled fp8 MFMA issues at the bf16 rate; what fp8 buys here is half the DMA / LDS bytes per FLOP.
+// Epilogues: bias -> bf16 ; bias + erf-GELU -> fp8 (times out_inv_scale, saturated to +-448) ; R + lam (.) (.) -> fp32.
+#include <cstdlib>
+
+#include "ldit_common.h"
+
+namespace ldit {
+
+namespace {
+
+typedef long i64x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_8 __attribute__((ext_vector_type(4)));
+constexpr int BKE = 128, ROW8 = 128;
+
+__device__ __forceinline__ void glds16q(const void *gsrc, char *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+struct GemmArgs8 {
+    const unsigned char *A, *W;   // fp8 e4m3
+    void *Y;                      // bf16 (BIAS) / fp8 (BIAS_GELU) / fp32 (SCALE_RESID)
+    float *Y2;                    // optional fp32 tap copy (SCALE_RESID)
+    const float *bias, *lam, *R;
+    int M, N, K, lda, ldy;
+    float ab_scale;               // sa * sw: dequantisation of the accumulator
+    float out_inv_scale;          // 1 / scale of the fp8 output (BIAS_GELU)
+    const float *d_ab, *d_out;    // device-resident {sa, sw} / {so}: override the two host values when non-null
+};
+
+template <int TM, int TN, int EPI, bool CHECK>
+__device__ __forceinline__ void store_q(const GemmArgs8 &p, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane)
+{
+    const int c32 = lane & 31, h = lane >> 5;
+    const bool dual = p.Y2 != nullptr;
+    const float ab = p.d_ab ? p.d_ab[0] * p.d_ab[1] : p.ab_scale;
+    const float oinv = (EPI == EPI_BIAS_GELU && p.d_out) ? 1.0f / p.d_out[0] : p.out_inv_scale;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        f32x4 bias[4], lam[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = nw + j * 32 + 8 * g + 4 * h + e;
+                const bool ok = !CHECK || n < p.N;
+                bias[g][e] = (ok && p.bias) ? p.bias[n] : 0.0f;
+                lam[g][e] = (EPI == EPI_SCALE_RESID && ok) ? p.lam[n] : 0.0f;
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = mw + i * 32 + c32;
+            if (CHECK && m >= p.M) continue;
+            f32x4 res[4];
+            if (EPI == EPI_SCALE_RESID) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nw + j * 32 + 8 * g + 4 * h;
+                    const unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
+                    if (!CHECK) res[g] = *reinterpret_cast<const f32x4 *>(p.R + o);
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) res[g][e] = (n + e < p.N) ? p.R[o + e] : 0.0f;
+                }
+                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nw + j * 32 + 8 * g + 4 * h;
+                const unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[i][j][4 * g + e] * ab + bias[g][e];
+                    if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
+                    if (EPI == EPI_SCALE_RESID) t = res[g][e] + lam[g][e] * t;
+                    v[e] = t;
+                }
+                if (EPI == EPI_SCALE_RESID) {
+                    float *y = static_cast<float *>(p.Y);
+                    if (!CHECK) {
+                        *reinterpret_cast<f32x4 *>(y + o) = v;
+                        if (dual) *reinterpret_cast<f32x4 *>(p.Y2 + o) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) { y[o + e] = v[e]; if (dual) p.Y2[o + e] = v[e]; }
+                    }
+                } else if (EPI == EPI_BIAS_GELU) {
+                    unsigned char *y = static_cast<unsigned char *>(p.Y);
+                    const unsigned pk = pack_fp8x4(v[0] * oinv, v[1] * oinv, v[2] * oinv, v[3] * oinv);
+                    if (!CHECK) *reinterpret_cast<unsigned *>(y + o) = pk;
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) y[o + e] = (unsigned char)(pk >> (8 * e));
+                } else {
+                    __bf16 *y = static_cast<__bf16 *>(p.Y);
+                    if (!CHECK) {
+                        const bf16x4_8 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        *reinterpret_cast<bf16x4_8 *>(y + o) = pk;
+                    } else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) y[o + e] = (__bf16)v[e];
+                }
+            }
+            if (EPI == EPI_SCALE_RESID) asm volatile("" ::: "memory");
+        }
+    }
+}
+
+// K64 = false: v_mfma_f32_32x32x16_fp8_fp8 (bf16 rate), two per b128 fragment read, four chunk steps per k-tile.
+// K64 = true : v_mfma_f32_32x32x64_f8f6f4 with e4m3 operands and unit block scales (2x the bf16 rate): a lane's operand is
+//              32 consecutive fp8 of its row (two b128 reads), two chunk steps per k-tile.
+template <int WM, int WN, int TM, int TN, int EPI, bool K64>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_fp8_mfma(const GemmArgs8 p)
+{
+    constexpr int NWAVES = WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, ROWS = BM + BN, NLD = ROWS / (8 * NWAVES);
+    static_assert(ROWS % (8 * NWAVES) == 0 && BM % 8 == 0, "DMA pieces must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int c32 = lane & 31, h = lane >> 5;
+
+    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+    const int ntiles = nbm * nbn;
+    int tile;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = ntiles >> 3, rr = ntiles & 7;
+        tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+
+    unsigned src[NLD];   // byte (= element) offsets
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int row = 8 * (wave + NWAVES * u) + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        if (8 * (wave + NWAVES * u) < BM) {
+            int gm = m0 + row;
+            gm = gm < p.M ? gm : p.M - 1;
+            src[u] = (unsigned)gm * (unsigned)p.lda + c * 16;
+        } else {
+            int gn = n0 + row - BM;
+            gn = gn < p.N ? gn : p.N - 1;
+            src[u] = (unsigned)gn * (unsigned)p.K + c * 16;
+        }
+    }
+    auto issue = [&](int stage, int k0) {
+        char *base = smem + stage * (ROWS * ROW8);
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int piece = wave + NWAVES * u;
+            const unsigned char *opnd = 8 * piece < BM ? p.A : p.W;
+            glds16q(opnd + (src[u] + (unsigned)k0), base + piece * 1024);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int sw = (c32 >> 1) & 7;
+    const int nk = p.K / BKE;
+    const int a_row = (wm * TM * 32 + c32) * ROW8, b_row = (BM + wn * TN * 32 + c32) * ROW8;
+
+    if constexpr (!K64) {
+        auto load_frags = [&](int stage, int c, i64x2(&xa)[TM], i64x2(&wb)[TN]) {
+            const char *base = smem + stage * (ROWS * ROW8) + ((c * 2 + h) ^ sw) * 16;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const i64x2 *>(base + a_row + i * 32 * ROW8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wb[j] = *reinterpret_cast<const i64x2 *>(base + b_row + j * 32 * ROW8);
+        };
+        auto mfma_chunk = [&](const i64x2(&xa)[TM], const i64x2(&wb)[TN]) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(wb[j][half], xa[i][half], acc[i][j], 0, 0, 0);
+        };
+        i64x2 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
+        issue(0, 0);
+        __syncthreads();
+        load_frags(0, 0, xa0, wb0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const int knext = (kt + 1 < nk ? kt + 1 : nk - 1) * BKE;
+            load_frags(cur, 1, xa1, wb1);
+            issue(cur ^ 1, knext);
+            mfma_chunk(xa0, wb0);
+            load_frags(cur, 2, xa0, wb0);
+            mfma_chunk(xa1, wb1);
+            load_frags(cur, 3, xa1, wb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk(xa0, wb0);
+            __syncthreads();   // hand-over: tile kt+1 landed in every wave, stage cur released
+            load_frags(cur ^ 1, 0, xa0, wb0);
+            mfma_chunk(xa1, wb1);
+        }
+    } else {
+        auto load_frags = [&](int stage, int c, i32x8(&xa)[TM], i32x8(&wb)[TN]) {
+            const char *base = smem + stage * (ROWS * ROW8);
+            const int o0 = ((4 * c + 2 * h) ^ sw) * 16, o1 = ((4 * c + 2 * h + 1) ^ sw) * 16;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const i32x4 lo = *reinterpret_cast<const i32x4 *>(base + a_row + i * 32 * ROW8 + o0);
+                const i32x4 hi = *reinterpret_cast<const i32x4 *>(base + a_row + i * 32 * ROW8 + o1);
+                xa[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const i32x4 lo = *reinterpret_cast<const i32x4 *>(base + b_row + j * 32 * ROW8 + o0);
+                const i32x4 hi = *reinterpret_cast<const i32x4 *>(base + b_row + j * 32 * ROW8 + o1);
+                wb[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        };
+        auto mfma_chunk = [&](const i32x8(&xa)[TM], const i32x8(&wb)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb[j], xa[i], acc[i][j], 0, 0, 0, 0, 0, 0);
+        };
+        i32x8 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
+        issue(0, 0);
+        __syncthreads();
+        load_frags(0, 0, xa0, wb0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const int knext = (kt + 1 < nk ? kt + 1 : nk - 1) * BKE;
+            load_frags(cur, 1, xa1, wb1);
+            issue(cur ^ 1, knext);
+            mfma_chunk(xa0, wb0);
+            __syncthreads();   // hand-over: tile kt+1 landed in every wave, stage cur released (its last reads are in xa1/wb1)
+            load_frags(cur ^ 1, 0, xa0, wb0);
+            mfma_chunk(xa1, wb1);
+        }
+    }
+
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
+    const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
+    if (interior) store_q<TM, TN, EPI, false>(p, acc, mw, nw, lane);
+    else store_q<TM, TN, EPI, true>(p, acc, mw, nw, lane);
+}
+
+template <int WM, int WN, int TM, int TN, int EPI, bool K64>
+int launch_q(const GemmArgs8 &a, hipStream_t stream)
+{
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int lds = 2 * (BM + BN) * ROW8;
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    auto kern = gemm_fp8_mfma<WM, WN, TM, TN, EPI, K64>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), lds, stream, a);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+// ---- skinny kernel: up to 64 rows (the ragged tail peeled off by launch_gemm_fp8; same scheme as gemm_bf16_skinny) ---------
+// A workgroup owns 64 rows x 64 columns and its eight waves split K: every wave multiplies the whole tile over K/8 with
+// 8-byte fragments loaded straight from global memory, the partial tiles are summed through LDS in a fixed order, then the
+// epilogue runs on 8 elements per thread.
+template <int EPI>
+__global__ void __launch_bounds__(512, 2) gemm_fp8_skinny(const GemmArgs8 p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *part = reinterpret_cast<float *>(smem);            // [8 waves][64 rows][64 cols]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c32 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 64;
+    const int kslice = p.K / 8, k0 = wave * kslice;
+
+    const unsigned char *ap[2], *wp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = 32 * t + c32, n = n0 + 32 * t + c32;
+        ap[t] = p.A + (size_t)(m < p.M ? m : p.M - 1) * p.lda + k0 + 8 * h;
+        wp[t] = p.W + (size_t)(n < p.N ? n : p.N - 1) * p.K + k0 + 8 * h;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    for (int s = 0; s < kslice / 16; ++s) {
+        long xa[2], wb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            xa[t] = *reinterpret_cast<const long *>(ap[t] + 16 * s);
+            wb[t] = *reinterpret_cast<const long *>(wp[t] + 16 * s);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(wb[j], xa[i], acc[i][j], 0, 0, 0);
+    }
+    float *mine = part + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(mine + (32 * i + c32) * 64 + 32 * j + 8 * g + 4 * h) = v;
+            }
+    __syncthreads();
+    const int row = tid >> 3, col = (tid & 7) * 8;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(part + w * 4096 + row * 64 + col);
+        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(part + w * 4096 + row * 64 + col + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s0[e] += a0[e]; s1[e] += a1[e]; }
+    }
+    if (row >= p.M) return;
+    const float ab = p.d_ab ? p.d_ab[0] * p.d_ab[1] : p.ab_scale;
+    const float oinv = (EPI == EPI_BIAS_GELU && p.d_out) ? 1.0f / p.d_out[0] : p.out_inv_scale;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int n = n0 + col + e;
+        if (n >= p.N) break;
+        float t = (e < 4 ? s0[e] : s1[e - 4]) * ab + (p.bias ? p.bias[n] : 0.0f);
+        const size_t o = (size_t)row * p.ldy + n;
+        if (EPI == EPI_BIAS_GELU) {
+            static_cast<unsigned char *>(p.Y)[o] = (unsigned char)pack_fp8x4(gelu_erf(t) * oinv, 0.f, 0.f, 0.f);
+        } else if (EPI == EPI_SCALE_RESID) {
+            t = p.R[o] + p.lam[n] * t;
+            static_cast<float *>(p.Y)[o] = t;
+            if (p.Y2) p.Y2[o] = t;
+        } else {
+            static_cast<__bf16 *>(p.Y)[o] = (__bf16)t;
+        }
+    }
+}
+
+template <int EPI>
+int launch_qskinny(const GemmArgs8 &a, hipStream_t stream)
+{
+    constexpr int lds = 8 * 4096 * 4;
+    auto kern = gemm_fp8_skinny<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((a.N + 63) / 64), dim3(512), lds, stream, a);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+template <int EPI>
+int launch_q_tiled(const GemmArgs8 &a, hipStream_t stream)
+{
+    // LDIT_GEMM_FP8_K16=1 selects the K = 16 MFMA, LDIT_GEMM_FP8_TILE=0..2 forces a tile (both for experiments / tests)
+    static const bool k16 = [] { const char *e = getenv("LDIT_GEMM_FP8_K16"); return e && *e == '1'; }();
+    static const bool noskinny = [] { const char *e = getenv("LDIT_GEMM_FP8_NOSKINNY"); return e && *e == '1'; }();
+    if (a.M <= 64 && !noskinny) return launch_qskinny<EPI>(a, stream);     // peeled tail / tiny batch: split-K
+    // cost model (as launch_h_tiled in gemm_bf16.hip): rounds of 256 workgroups x tile area / relative tile efficiency
+    struct Cand { int bm, bn, id; double eff; };
+    const Cand cands[3] = {{256, 256, 0, 1.0}, {256, 128, 1, 0.7}, {128, 128, 2, 0.5}};
+    double best = -1.0;
+    int pick = 2;
+    for (const Cand &c : cands) {
+        const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
+        const double cost = (double)((tiles + 255) / 256) * c.bm * c.bn / c.eff;
+        if (best < 0 || cost < best) { best = cost; pick = c.id; }
+    }
+    if (const char *force = getenv("LDIT_GEMM_FP8_TILE"))
+        if (force[0] >= '0' && force[0] <= '2' && force[1] == 0) pick = force[0] - '0';
+    if (k16) {
+        if (pick == 0) return launch_q<2, 4, 4, 2, EPI, false>(a, stream);
+        if (pick == 1) return launch_q<2, 2, 4, 2, EPI, false>(a, stream);
+        return launch_q<2, 2, 2, 2, EPI, false>(a, stream);
+    }
+    if (pick == 0) return launch_q<2, 4, 4, 2, EPI, true>(a, stream);      // 256 x 256, 8 waves
+    if (pick == 1) return launch_q<2, 2, 4, 2, EPI, true>(a, stream);      // 256 x 128, 4 waves
+    return launch_q<2, 2, 2, 2, EPI, true>(a, stream);                     // 128 x 128, 4 waves
+}
+
+// dst[i] = fp8(src[i] * inv_scale), saturating; 4 elements per thread
+__global__ void __launch_bounds__(256) quant_fp8(const float *__restrict__ src, unsigned char *__restrict__ dst, size_t n,
+                                                 float inv_scale, const float *__restrict__ d_scale)
+{
+    if (d_scale) inv_scale = 1.0f / d_scale[0];
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + i);
+        *reinterpret_cast<unsigned *>(dst + i) = pack_fp8x4(v[0] * inv_scale, v[1] * inv_scale, v[2] * inv_scale, v[3] * inv_scale);
+    } else {
+        for (size_t k = i; k < n; ++k) dst[k] = (unsigned char)pack_fp8x4(src[k] * inv_scale, 0.f, 0.f, 0.f);
+    }
+}
+
+// *out = max(*out, max |src|): non-negative floats order like their bit patterns, so one integer atomicMax per block
+__global__ void __launch_bounds__(256) amax_f32(const float *__restrict__ src, size_t n, unsigned *__restrict__ out)
+{
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(src[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        atomicMax(out, __float_as_uint(m));
+    }
+}
+
+
+__global__ void amax_to_scale(float *p, int n)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) p[i] = fmaxf(p[i], 1e-30f) * (1.0f / 448.0f);
+}
+
+}  // namespace
+
+static int launch_gemm_fp8_one(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K,
+                               int epi, const float *lam, const float *R, float *Y2, float ab_scale, float out_inv_scale,
+                               const float *d_ab, const float *d_out, hipStream_t stream);
+
+// A ragged tail of up to 64 rows past a multiple of the 256-row tile is peeled off into a second, tiny launch (see
+// launch_gemm_bf16): M = 16 x 1025 = 64 x 256 + 16 would otherwise cost a whole extra round of workgroups.
+int launch_gemm_fp8(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
+                    const float *lam, const float *R, float *Y2, float ab_scale, float out_inv_scale, const float *d_ab,
+                    const float *d_out, hipStream_t stream)
+{
+    const int rem = M % 256;
+    const long nbn = (N + 255) / 256, full = ((long)M / 256 + 1) * nbn, mainp = ((long)M / 256) * nbn;
+    if (rem != 0 && rem <= 64 && M > 256 && (full + 255) / 256 > (mainp + 255) / 256) {   // peel only when it saves a round
+        const int main_rows = M - rem;
+        const size_t out_elt = epi == EPI_SCALE_RESID ? 4 : epi == EPI_BIAS_GELU ? 1 : 2;
+        int rc = launch_gemm_fp8_one(A, lda, W, bias, Y, ldy, main_rows, N, K, epi, lam, R, Y2, ab_scale, out_inv_scale, d_ab, d_out, stream);
+        if (rc != LDIT_OK) return rc;
+        const char *At = static_cast<const char *>(A) + (size_t)main_rows * lda;
+        char *Yt = static_cast<char *>(Y) + (size_t)main_rows * ldy * out_elt;
+        return launch_gemm_fp8_one(At, lda, W, bias, Yt, ldy, rem, N, K, epi, lam, R ? R + (size_t)main_rows * ldy : nullptr,
+                                   Y2 ? Y2 + (size_t)main_rows * ldy : nullptr, ab_scale, out_inv_scale, d_ab, d_out, stream);
+    }
+    return launch_gemm_fp8_one(A, lda, W, bias, Y, ldy, M, N, K, epi, lam, R, Y2, ab_scale, out_inv_scale, d_ab, d_out, stream);
+}
+
+static int launch_gemm_fp8_one(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K,
+                               int epi, const float *lam, const float *R, float *Y2, float ab_scale, float out_inv_scale,
+                               const float *d_ab, const float *d_out, hipStream_t stream)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return fail(LDIT_EINVAL, "gemm_fp8: empty problem");
+    if (K % BKE) return fail(LDIT_EUNSUPPORTED, "gemm_fp8: K=%d must be a multiple of %d", K, BKE);
+    if (!A || !W || !Y) return fail(LDIT_EINVAL, "gemm_fp8: null operand");
+    if (!aligned16(A) || !aligned16(W) || (lda & 15)) return fail(LDIT_EINVAL, "gemm_fp8: operands must be 16-byte aligned");
+    GemmArgs8 a{};
+    a.A = static_cast<const unsigned char *>(A); a.W = static_cast<const unsigned char *>(W); a.Y = Y; a.Y2 = Y2;
+    a.bias = bias; a.lam = lam; a.R = R; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldy = ldy;
+    a.ab_scale = ab_scale; a.out_inv_scale = out_inv_scale; a.d_ab = d_ab; a.d_out = d_out;
+    switch (epi) {
+        case EPI_BIAS: return launch_q_tiled<EPI_BIAS>(a, stream);
+        case EPI_BIAS_GELU: return launch_q_tiled<EPI_BIAS_GELU>(a, stream);
+        case EPI_SCALE_RESID:
+            if (!lam || !R) return fail(LDIT_EINVAL, "gemm_fp8: scale+residual epilogue needs lam and R");
+            return launch_q_tiled<EPI_SCALE_RESID>(a, stream);
+        default: return fail(LDIT_EINVAL, "gemm_fp8: unknown epilogue %d", epi);
+    }
+}
+
+int launch_quant_fp8(const float *src, void *dst, size_t n, float inv_scale, const float *d_scale, hipStream_t stream)
+{
+    if (n == 0) return LDIT_OK;
+    hipLaunchKernelGGL(quant_fp8, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream, src,
+                       static_cast<unsigned char *>(dst), n, inv_scale, d_scale);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+int launch_amax_to_scale(float *p, int n, hipStream_t stream)
+{
+    if (n <= 0) return LDIT_OK;
+    hipLaunchKernelGGL(amax_to_scale, dim3((n + 63) / 64), dim3(64), 0, stream, p, n);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+int launch_amax_f32(const float *src, size_t n, float *out, bool accumulate, hipStream_t stream)
+{
+    if (!accumulate) LDIT_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float), stream));
+    if (n == 0) return LDIT_OK;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(amax_f32, dim3(blocks), dim3(256), 0, stream, src, n, reinterpret_cast<unsigned *>(out));
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+}  // namespace ldit

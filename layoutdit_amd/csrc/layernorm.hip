@@ -19,11 +19,12 @@ __device__ __forceinline__ float wave_sum(float v)
 // VPL = float4 vectors per lane; handles C <= 256 * VPL
 typedef __bf16 ln_bf16x4 __attribute__((ext_vector_type(4)));
 
-// OUT_BF16: the normalised row is rounded to bf16 (operand of the bf16 GEMMs); statistics and affine stay fp32.
-template <int VPL, bool OUT_BF16>
+// OUT = 1: the normalised row is rounded to bf16 (operand of the bf16 GEMMs); OUT = 2: quantised to fp8 e4m3 codes of
+// y / *qscale (operand of the fp8 GEMMs, saturating); statistics and affine stay fp32.
+template <int VPL, int OUT>
 __global__ void __launch_bounds__(256) layernorm_rows(const float *__restrict__ X, const float *__restrict__ g,
                                                       const float *__restrict__ b, void *__restrict__ Yv, int64_t rows,
-                                                      int C, float eps)
+                                                      int C, float eps, const float *__restrict__ qscale)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -69,7 +70,11 @@ __global__ void __launch_bounds__(256) layernorm_rows(const float *__restrict__ 
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = v[u][e] * rstd * gg[e] + bb[e];
-            if (OUT_BF16) {
+            if (OUT == 2) {
+                const float qi = 1.0f / qscale[0];
+                reinterpret_cast<unsigned *>(static_cast<unsigned char *>(Yv) + row * C)[idx] =
+                    pack_fp8x4(o[0] * qi, o[1] * qi, o[2] * qi, o[3] * qi);
+            } else if (OUT == 1) {
                 const ln_bf16x4 pk = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
                 reinterpret_cast<ln_bf16x4 *>(static_cast<__bf16 *>(Yv) + row * C)[idx] = pk;
             } else {
@@ -81,18 +86,19 @@ __global__ void __launch_bounds__(256) layernorm_rows(const float *__restrict__ 
 
 }  // namespace
 
-template <bool OUT_BF16>
-static int launch_ln(const float *X, const float *g, const float *b, void *Y, int64_t rows, int C, float eps, hipStream_t stream)
+template <int OUT>
+static int launch_ln(const float *X, const float *g, const float *b, void *Y, int64_t rows, int C, float eps,
+                     const float *qscale, hipStream_t stream)
 {
     if (rows <= 0 || C <= 0) return fail(LDIT_EINVAL, "layernorm: empty problem");
     if (!X || !g || !b || !Y) return fail(LDIT_EINVAL, "layernorm: null operand");
     if (C & 3) return fail(LDIT_EUNSUPPORTED, "layernorm: C=%d must be a multiple of 4", C);
     if (C > 4096) return fail(LDIT_EUNSUPPORTED, "layernorm: C=%d exceeds 4096", C);
-    if (!aligned16(X) || (reinterpret_cast<uintptr_t>(Y) & 7u) || !aligned16(g) || !aligned16(b)) return fail(LDIT_EINVAL, "layernorm: operands must be 16-byte aligned");
+    if (!aligned16(X) || (reinterpret_cast<uintptr_t>(Y) & (OUT == 2 ? 3u : 7u)) || !aligned16(g) || !aligned16(b)) return fail(LDIT_EINVAL, "layernorm: operands must be 16-byte aligned");
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    if (C <= 256) hipLaunchKernelGGL((layernorm_rows<1, OUT_BF16>), grid, block, 0, stream, X, g, b, Y, rows, C, eps);
-    else if (C <= 1024) hipLaunchKernelGGL((layernorm_rows<4, OUT_BF16>), grid, block, 0, stream, X, g, b, Y, rows, C, eps);
-    else hipLaunchKernelGGL((layernorm_rows<16, OUT_BF16>), grid, block, 0, stream, X, g, b, Y, rows, C, eps);
+    if (C <= 256) hipLaunchKernelGGL((layernorm_rows<1, OUT>), grid, block, 0, stream, X, g, b, Y, rows, C, eps, qscale);
+    else if (C <= 1024) hipLaunchKernelGGL((layernorm_rows<4, OUT>), grid, block, 0, stream, X, g, b, Y, rows, C, eps, qscale);
+    else hipLaunchKernelGGL((layernorm_rows<16, OUT>), grid, block, 0, stream, X, g, b, Y, rows, C, eps, qscale);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }
@@ -100,13 +106,20 @@ static int launch_ln(const float *X, const float *g, const float *b, void *Y, in
 int launch_layernorm(const float *X, const float *g, const float *b, float *Y, int64_t rows, int C, float eps,
                      hipStream_t stream)
 {
-    return launch_ln<false>(X, g, b, Y, rows, C, eps, stream);
+    return launch_ln<0>(X, g, b, Y, rows, C, eps, nullptr, stream);
 }
 
 int launch_layernorm_bf16out(const float *X, const float *g, const float *b, void *Y, int64_t rows, int C, float eps,
                              hipStream_t stream)
 {
-    return launch_ln<true>(X, g, b, Y, rows, C, eps, stream);
+    return launch_ln<1>(X, g, b, Y, rows, C, eps, nullptr, stream);
+}
+
+int launch_layernorm_fp8out(const float *X, const float *g, const float *b, void *Y, int64_t rows, int C, float eps,
+                            const float *qscale, hipStream_t stream)
+{
+    if (!qscale) return fail(LDIT_EINVAL, "layernorm: fp8 output needs a scale");
+    return launch_ln<2>(X, g, b, Y, rows, C, eps, qscale, stream);
 }
 
 }  // namespace ldit

@@ -53,6 +53,18 @@ __device__ __forceinline__ float erf_fast(float a)
 // exact (erf) GELU of TF:activations.py:70-89
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f)); }
 
+// 4 floats -> 4 fp8 e4m3 (round to nearest even, saturating at +-448), packed little-endian in one dword
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d)
+{
+    const float lim = 448.0f;
+    a = fminf(fmaxf(a, -lim), lim); b = fminf(fmaxf(b, -lim), lim);
+    c = fminf(fmaxf(c, -lim), lim); d = fminf(fmaxf(d, -lim), lim);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+
 // ---- GEMM ----------------------------------------------------------------------------------------------------
 enum AMode { A_ROWMAJOR = 0, A_PATCH = 1 };
 enum Epi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_SCALE_RESID = 2, EPI_EMBED = 3 };
@@ -94,6 +106,18 @@ int launch_preprocess(const float *const *images, const int *heights, const int 
 int launch_gemm_bf16(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
                      const float *lam, const float *R, float *Y2, hipStream_t stream);
 int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream);
+// fp8: d_ab (device, 2 floats: activation scale, weight scale) and d_out (device, 1 float: scale of the fp8 output) take
+// precedence over the host values ab_scale / out_inv_scale when non-null.
+int launch_gemm_fp8(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
+                    const float *lam, const float *R, float *Y2, float ab_scale, float out_inv_scale, const float *d_ab,
+                    const float *d_out, hipStream_t stream);
+int launch_quant_fp8(const float *src, void *dst, size_t n, float inv_scale, const float *d_scale, hipStream_t stream);
+int launch_amax_f32(const float *src, size_t n, float *out, bool accumulate, hipStream_t stream);
+int launch_amax_to_scale(float *p, int n, hipStream_t stream);   // p[i] = max(p[i], tiny) / 448
+int launch_layernorm_fp8out(const float *X, const float *g, const float *b, void *Y, int64_t rows, int C, float eps,
+                            const float *qscale, hipStream_t stream);
+int launch_attention_bf16_fp8out(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ldq,
+                                 int ldk, int ldv, int ldo, float scale, const float *qscale, hipStream_t stream);
 int launch_pack_qkv_bias(const float *bq, const float *bv, float *dst, int C, hipStream_t stream);
 
 }  // namespace ldit

@@ -37,6 +37,9 @@ class _Affine(nn.Module):
             self.register_parameter("bias", None)
 
 
+_DTYPES = {"f32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16, "fp8": _lib.DTYPE_FP8}
+
+
 class _Holder(nn.Module):
     pass
 
@@ -52,11 +55,13 @@ class DiTEncoderOutput:
 
 class DiTEncoder(nn.Module):
     def __init__(self, config: Optional[DiTConfig] = None, compute_dtype: str = "f32"):
-        """``compute_dtype``: ``"f32"`` (exact-fp32 MFMA, the parity path) or ``"bf16"`` (bf16 GEMM / attention operands
-        with fp32 accumulation, residual stream, LayerNorm and softmax; parameters and returned taps stay fp32)."""
+        """``compute_dtype``: ``"f32"`` (exact-fp32 MFMA, the parity path), ``"bf16"`` (bf16 GEMM / attention operands
+        with fp32 accumulation, residual stream, LayerNorm and softmax; parameters and returned taps stay fp32) or
+        ``"fp8"`` (the four GEMMs of a layer on fp8 e4m3 operands with per-tensor scales, attention on bf16; needs one
+        ``calibrate_fp8(sample_batch)`` call before the first forward)."""
         super().__init__()
-        if compute_dtype not in ("f32", "bf16"):
-            raise ValueError(f"compute_dtype {compute_dtype!r}: expected 'f32' or 'bf16'")
+        if compute_dtype not in _DTYPES:
+            raise ValueError(f"compute_dtype {compute_dtype!r}: expected 'f32', 'bf16' or 'fp8'")
         self.compute_dtype = compute_dtype
         self.config = config or DiTConfig()
         cfg = self.config
@@ -95,6 +100,9 @@ class DiTEncoder(nn.Module):
         self.pooler.layernorm = _Affine(Cc)                              # inert: kept for key compatibility
         self.reset_parameters()
 
+        # fp8 activation scales [L, 4] (order: enum ldit_fp8_act); zeros = not calibrated.  Not part of state_dict():
+        # the checkpoint stays key-compatible with BeitModel.
+        self.register_buffer("fp8_act_scales", torch.zeros(cfg.num_hidden_layers, _lib.FP8_A_COUNT), persistent=False)
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
         self._workspace: Optional[torch.Tensor] = None
@@ -130,7 +138,7 @@ class DiTEncoder(nn.Module):
         c = _lib.LditCfg(hidden=cfg.hidden_size, layers=cfg.num_hidden_layers, heads=cfg.num_attention_heads,
                          mlp=cfg.intermediate_size, patch=cfg.patch_size, in_ch=cfg.num_channels, img_h=img_h,
                          img_w=img_w, n_taps=len(taps), ln_eps=cfg.layer_norm_eps,
-                         dtype=_lib.DTYPE_BF16 if self.compute_dtype == "bf16" else _lib.DTYPE_F32, flags=0)
+                         dtype=_DTYPES[self.compute_dtype], flags=0)
         for i, t in enumerate(taps):
             c.taps[i] = t
         return c
@@ -158,7 +166,7 @@ class DiTEncoder(nn.Module):
     def _pack(self, lcfg: _lib.LditCfg, pos: torch.Tensor, device: torch.device) -> torch.Tensor:
         params = [p for p in self.parameters()]
         key = (str(device), lcfg.img_h, lcfg.img_w, lcfg.dtype, pos.data_ptr(),
-               tuple((p.data_ptr(), p._version) for p in params))
+               tuple((p.data_ptr(), p._version) for p in params), self.fp8_act_scales._version)
         if self._packed is not None and self._packed_key == key:
             return self._packed
         lib = _lib.load()
@@ -197,8 +205,54 @@ class DiTEncoder(nn.Module):
                              pos=ptr(pos), layer=layers)
         _lib.check(lib.ldit_pack_weights(C.byref(lcfg), C.byref(w), packed.data_ptr(), nbytes,
                                          torch.cuda.current_stream(device).cuda_stream))
+        if lcfg.dtype == _lib.DTYPE_FP8:
+            sc = self.fp8_act_scales.detach().to("cpu", torch.float32).contiguous()
+            if not bool((sc > 0).all()):
+                raise RuntimeError("compute_dtype='fp8': activation scales are not calibrated - call "
+                                   "calibrate_fp8(sample_pixel_values) once (or assign fp8_act_scales) before the forward")
+            arr = (C.c_float * sc.numel())(*sc.reshape(-1).tolist())
+            _lib.check(lib.ldit_set_fp8_act_scales(C.byref(lcfg), packed.data_ptr(), nbytes, arr,
+                                                   torch.cuda.current_stream(device).cuda_stream))
         self._packed, self._packed_key = packed, key
         return packed
+
+    @torch.no_grad()
+    def calibrate_fp8(self, pixel_values: torch.Tensor, margin: float = 1.0) -> torch.Tensor:
+        """Measure the four per-layer activation ranges of the fp8 build on a sample batch and store
+        ``scale = margin * amax / 448`` in ``fp8_act_scales``.  Host-side sequencing of the library's own fp32 kernels
+        (``layoutdit_amd.ops``), layer by layer, so the statistics are those of the exact path."""
+        from .. import ops
+        cfg = self.config
+        if not pixel_values.is_cuda:
+            raise RuntimeError("calibrate_fp8 runs on the GPU kernels: move the sample batch to a HIP device")
+        x = pixel_values.detach().to(torch.float32).contiguous()
+        B, _, H, W = x.shape
+        p, Cc, Hh = cfg.patch_size, cfg.hidden_size, cfg.num_attention_heads
+        pos = self._position_table(H // p, W // p).contiguous()
+        proj = self.embeddings.patch_embeddings.projection
+        h = ops.embed(x, proj.weight.detach().contiguous(), proj.bias.detach(), self.embeddings.cls_token.detach().reshape(-1),
+                      pos, p)
+        T = h.shape[1]
+        h = h.reshape(B * T, Cc)
+        amax = []
+        for blk in self.encoder.layer:
+            a = blk.attention.attention
+            y = ops.layernorm(h, blk.layernorm_before.weight.detach(), blk.layernorm_before.bias.detach(), cfg.layer_norm_eps)
+            wqkv = torch.cat([a.query.weight, a.key.weight, a.value.weight]).detach().contiguous()
+            bqkv = torch.cat([a.query.bias, torch.zeros_like(a.query.bias), a.value.bias]).detach().contiguous()
+            qkv = ops.linear(y, wqkv, bqkv).reshape(B, T, 3 * Cc)
+            o = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], Hh).reshape(B * T, Cc)
+            h = ops.linear(o, blk.attention.output.dense.weight.detach(), blk.attention.output.dense.bias.detach(),
+                           epilogue=_lib.EPI_SCALE_RESID, lam=blk.lambda_1.detach(), residual=h, out=h)
+            y2 = ops.layernorm(h, blk.layernorm_after.weight.detach(), blk.layernorm_after.bias.detach(), cfg.layer_norm_eps)
+            g = ops.linear(y2, blk.intermediate.dense.weight.detach(), blk.intermediate.dense.bias.detach(),
+                           epilogue=_lib.EPI_BIAS_GELU)
+            h = ops.linear(g, blk.output.dense.weight.detach(), blk.output.dense.bias.detach(),
+                           epilogue=_lib.EPI_SCALE_RESID, lam=blk.lambda_2.detach(), residual=h, out=h)
+            amax.append(torch.cat([ops.amax(y), ops.amax(o), ops.amax(y2), ops.amax(g)]))
+        scales = torch.stack(amax).clamp_min(1e-20) * (float(margin) / ops.FP8_MAX)
+        self.fp8_act_scales.copy_(scales)
+        return self.fp8_act_scales
 
     def _scratch(self, lcfg: _lib.LditCfg, batch: int, device: torch.device) -> torch.Tensor:
         need = _lib.load().ldit_workspace_bytes(C.byref(lcfg), batch)

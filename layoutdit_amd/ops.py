@@ -150,6 +150,49 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     return out
 
 
+FP8_MAX = 448.0          # largest finite e4m3 magnitude
+
+
+def amax(x: torch.Tensor) -> torch.Tensor:
+    """max |x| as a one-element fp32 GPU tensor (no host sync)."""
+    lib = _lib.load()
+    x = _req(x, "x")
+    out = torch.empty(1, device=x.device, dtype=torch.float32)
+    _lib.check(lib.ldit_amax_f32(_ptr(x), x.numel(), _ptr(out), _stream()))
+    return out
+
+
+def quant_fp8(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """fp32 -> fp8 e4m3 codes of ``x / scale`` (round to nearest even, saturating at +-448)."""
+    lib = _lib.load()
+    x = _req(x, "x")
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float8_e4m3fn)
+    _lib.check(lib.ldit_quant_f32_fp8(_ptr(x), _ptr(out), x.numel(), 1.0 / float(scale), _stream()))
+    return out
+
+
+def linear_fp8(x: torch.Tensor, weight: torch.Tensor, ab_scale: float, bias: Optional[torch.Tensor] = None,
+               epilogue: int = _lib.EPI_BIAS, lam: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out_scale: float = 1.0) -> torch.Tensor:
+    """fp8 MFMA GEMM: ``x`` [M, K], ``weight`` [N, K] fp8 e4m3 codes, ``ab_scale`` = scale_x * scale_w; bf16 result for the
+    bias epilogue, fp8 codes of ``gelu(.) / out_scale`` for the GELU epilogue, fp32 for the scale+residual epilogue."""
+    lib = _lib.load()
+    for t, n in ((x, "x"), (weight, "weight")):
+        if not t.is_cuda or t.dtype != torch.float8_e4m3fn or not t.is_contiguous():
+            raise ValueError(f"{n}: expected a contiguous float8_e4m3fn GPU tensor")
+    M, K = x.shape
+    N = weight.shape[0]
+    if out is None:
+        dt = {_lib.EPI_BIAS: torch.bfloat16, _lib.EPI_BIAS_GELU: torch.float8_e4m3fn, _lib.EPI_SCALE_RESID: torch.float32}[epilogue]
+        out = torch.empty((M, N), device=x.device, dtype=dt)
+    for t, n in ((bias, "bias"), (lam, "lam"), (residual, "residual"), (out2, "out2")):
+        if t is not None:
+            _req(t, n)
+    _lib.check(lib.ldit_linear_fp8(_ptr(x), K, _ptr(weight), _ptr(bias), _ptr(out), N, M, N, K, epilogue, _ptr(lam),
+                                   _ptr(residual), _ptr(out2), float(ab_scale), 1.0 / float(out_scale), _stream()))
+    return out
+
+
 def attention_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None) -> torch.Tensor:
     """bf16 fused attention; ``q, k, v``: bf16 [B, N, H*D] token-major (column slices of a fused tensor are fine)."""
     lib = _lib.load()
