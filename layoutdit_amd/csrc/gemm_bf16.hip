@@ -45,7 +45,10 @@ struct GemmArgsH {
     int M, N, K, lda, ldy;
 };
 
-template <int TM, int TN, int EPI, bool CHECK>
+// MODE 0: tile inside the matrix, 16-B / 8-B accesses unchecked; MODE 1: columns inside, rows past M skipped (the ragged
+// last row tile keeps its vector accesses - a lane owns a row, so the element-wise path does not coalesce and cost ~20 us);
+// MODE 2: element-wise with checks.
+template <int TM, int TN, int EPI, int MODE>
 __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane)
 {
     const int c32 = lane & 31, h = lane >> 5;
@@ -58,21 +61,21 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n = nw + j * 32 + 8 * g + 4 * h + e;
-                const bool ok = !CHECK || n < p.N;
+                const bool ok = MODE != 2 || n < p.N;
                 bias[g][e] = (ok && p.bias) ? p.bias[n] : 0.0f;
                 lam[g][e] = (EPI == EPI_SCALE_RESID && ok) ? p.lam[n] : 0.0f;
             }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = mw + i * 32 + c32;
-            if (CHECK && m >= p.M) continue;
+            if (MODE != 0 && m >= p.M) continue;
             f32x4 res[4];
             if (EPI == EPI_SCALE_RESID) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = nw + j * 32 + 8 * g + 4 * h;
                     const unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
-                    if (!CHECK) res[g] = *reinterpret_cast<const f32x4 *>(p.R + o);
+                    if (MODE != 2) res[g] = *reinterpret_cast<const f32x4 *>(p.R + o);
                     else
 #pragma unroll
                         for (int e = 0; e < 4; ++e) res[g][e] = (n + e < p.N) ? p.R[o + e] : 0.0f;
@@ -93,7 +96,7 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
                 }
                 if (EPI == EPI_SCALE_RESID) {
                     float *y = static_cast<float *>(p.Y);
-                    if (!CHECK) {
+                    if (MODE != 2) {
                         *reinterpret_cast<f32x4 *>(y + o) = v;
                         if (dual) *reinterpret_cast<f32x4 *>(p.Y2 + o) = v;
                     } else {
@@ -103,7 +106,7 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
                     }
                 } else {
                     bf16_t *y = static_cast<bf16_t *>(p.Y);
-                    if (!CHECK) {
+                    if (MODE != 2) {
                         const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
                         *reinterpret_cast<bf16x4 *>(y + o) = pk;
                     } else {
@@ -283,10 +286,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches of the tail must not outlive the LDS allocation
 
-    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
+    const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
-    if (interior) store_h<TM, TN, EPI, false>(p, acc, mw, nw, lane);
-    else store_h<TM, TN, EPI, true>(p, acc, mw, nw, lane);
+    if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
+    else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
+    else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
 }
 
 template <int WM, int WN, int TM, int TN, int EPI>
@@ -407,10 +411,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) gemm_bf16_ring(co
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail re-fetches must not outlive the LDS allocation
 
-    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
+    const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
-    if (interior) store_h<TM, TN, EPI, false>(p, acc, mw, nw, lane);
-    else store_h<TM, TN, EPI, true>(p, acc, mw, nw, lane);
+    if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
+    else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
+    else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
 }
 
 template <int WM, int WN, int TM, int TN, int STAGES, int EPI>
@@ -547,10 +552,11 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_pp(const GemmArgsH p)
     if (wm == 0) __builtin_amdgcn_s_barrier();                       // pairs with G1's extra barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail re-fetches must not outlive the LDS allocation
 
-    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
+    const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
-    if (interior) store_h<TM, TN, EPI, false>(p, acc, mw, nw, lane);
-    else store_h<TM, TN, EPI, true>(p, acc, mw, nw, lane);
+    if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
+    else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
+    else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
 }
 
 template <int EPI>
@@ -675,18 +681,19 @@ template <int EPI>
 int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
 {
     if (a.M <= 64 && a.K % 128 == 0 && !getenv("LDIT_GEMM_BF16_TILE")) return launch_skinny<EPI>(a, stream);
-    struct Cand { int bm, bn, id; double eff; };
-    // (a 288 x 256 four-wave "panel" instantiation <1,4,9,2> fixes the tile quantisation at M = 16 x 1025 but needs the
+    // Time model fitted to scripts/gemm_bf16_bench.py on ViT-B / ViT-L shapes, M = 3 k .. 25 k (profiles/README.md), in us:
+    //   256 x 256, 8 waves (one workgroup per CU):  strict rounds of 256 tiles, each  a[epi] + 19.5e-3 K
+    //   128 x 128 (two per CU, they overlap each other's prologue / epilogue):  rounds of 256 tiles, each  r[epi] + 7.6e-3 K,
+    //   but never less than one tile's own latency  5 + 11.4e-3 K.
+    // (256 x 128 and the ring / ping-pong variants never won a shape by more than a few percent: kept for experiments only.
+    //  A 288 x 256 four-wave "panel" instantiation <1,4,9,2> fixes the tile quantisation at M = 16 x 1025 but needs the
     //  pinned DMA/read schedule of gemm_panel_f32.hip to pay off: naive it spills and ran 439 vs 599 TFLOP/s)
-    const Cand cands[4] = {{256, 256, 3, 1.0}, {256, 256, 0, 0.8}, {256, 128, 1, 0.7}, {128, 128, 2, 0.5}};
-    double best = -1.0;
-    int pick = 2;
-    for (const Cand &c : cands) {
-        const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
-        const long rounds = (tiles + 255) / 256;
-        const double cost = (double)rounds * c.bm * c.bn / c.eff;
-        if (best < 0 || cost < best) { best = cost; pick = c.id; }
-    }
+    const double a256[3] = {19.0, 18.5, 25.0}, r128[3] = {5.2, 5.0, 7.7};
+    const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const double c256 = (double)((t256 + 255) / 256) * (a256[EPI] + 19.5e-3 * a.K);
+    double c128 = (double)((t128 + 255) / 256) * (r128[EPI] + 7.6e-3 * a.K);
+    if (c128 < 5.0 + 11.4e-3 * a.K) c128 = 5.0 + 11.4e-3 * a.K;
+    int pick = c256 <= c128 ? 3 : 2;
     if (const char *force = getenv("LDIT_GEMM_BF16_TILE")) {
         if (force[0] >= '0' && force[0] <= '6' && force[1] == 0) pick = force[0] - '0';
     }

@@ -38,7 +38,10 @@ struct GemmArgs8 {
     const float *d_ab, *d_out;    // device-resident {sa, sw} / {so}: override the two host values when non-null
 };
 
-template <int TM, int TN, int EPI, bool CHECK>
+// MODE 0: tile inside the matrix, 16-B / 8-B accesses unchecked; MODE 1: columns inside, rows past M skipped (the ragged
+// last row tile keeps its vector accesses - a lane owns a row, so the element-wise path does not coalesce and cost ~20 us);
+// MODE 2: element-wise with checks.
+template <int TM, int TN, int EPI, int MODE>
 __device__ __forceinline__ void store_q(const GemmArgs8 &p, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane)
 {
     const int c32 = lane & 31, h = lane >> 5;
@@ -53,21 +56,21 @@ __device__ __forceinline__ void store_q(const GemmArgs8 &p, const f32x16 (&acc)[
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n = nw + j * 32 + 8 * g + 4 * h + e;
-                const bool ok = !CHECK || n < p.N;
+                const bool ok = MODE != 2 || n < p.N;
                 bias[g][e] = (ok && p.bias) ? p.bias[n] : 0.0f;
                 lam[g][e] = (EPI == EPI_SCALE_RESID && ok) ? p.lam[n] : 0.0f;
             }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = mw + i * 32 + c32;
-            if (CHECK && m >= p.M) continue;
+            if (MODE != 0 && m >= p.M) continue;
             f32x4 res[4];
             if (EPI == EPI_SCALE_RESID) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = nw + j * 32 + 8 * g + 4 * h;
                     const unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
-                    if (!CHECK) res[g] = *reinterpret_cast<const f32x4 *>(p.R + o);
+                    if (MODE != 2) res[g] = *reinterpret_cast<const f32x4 *>(p.R + o);
                     else
 #pragma unroll
                         for (int e = 0; e < 4; ++e) res[g][e] = (n + e < p.N) ? p.R[o + e] : 0.0f;
@@ -88,7 +91,7 @@ __device__ __forceinline__ void store_q(const GemmArgs8 &p, const f32x16 (&acc)[
                 }
                 if (EPI == EPI_SCALE_RESID) {
                     float *y = static_cast<float *>(p.Y);
-                    if (!CHECK) {
+                    if (MODE != 2) {
                         *reinterpret_cast<f32x4 *>(y + o) = v;
                         if (dual) *reinterpret_cast<f32x4 *>(p.Y2 + o) = v;
                     } else {
@@ -99,14 +102,14 @@ __device__ __forceinline__ void store_q(const GemmArgs8 &p, const f32x16 (&acc)[
                 } else if (EPI == EPI_BIAS_GELU) {
                     unsigned char *y = static_cast<unsigned char *>(p.Y);
                     const unsigned pk = pack_fp8x4(v[0] * oinv, v[1] * oinv, v[2] * oinv, v[3] * oinv);
-                    if (!CHECK) *reinterpret_cast<unsigned *>(y + o) = pk;
+                    if (MODE != 2) *reinterpret_cast<unsigned *>(y + o) = pk;
                     else
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (n + e < p.N) y[o + e] = (unsigned char)(pk >> (8 * e));
                 } else {
                     __bf16 *y = static_cast<__bf16 *>(p.Y);
-                    if (!CHECK) {
+                    if (MODE != 2) {
                         const bf16x4_8 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                         *reinterpret_cast<bf16x4_8 *>(y + o) = pk;
                     } else
@@ -258,10 +261,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_fp8_mfma(con
         }
     }
 
-    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
+    const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
-    if (interior) store_q<TM, TN, EPI, false>(p, acc, mw, nw, lane);
-    else store_q<TM, TN, EPI, true>(p, acc, mw, nw, lane);
+    if (cols_in && m0 + BM <= p.M) store_q<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
+    else if (cols_in) store_q<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
+    else store_q<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
 }
 
 template <int WM, int WN, int TM, int TN, int EPI, bool K64>
@@ -388,16 +392,16 @@ int launch_q_tiled(const GemmArgs8 &a, hipStream_t stream)
     static const bool k16 = [] { const char *e = getenv("LDIT_GEMM_FP8_K16"); return e && *e == '1'; }();
     static const bool noskinny = [] { const char *e = getenv("LDIT_GEMM_FP8_NOSKINNY"); return e && *e == '1'; }();
     if (a.M <= 64 && !noskinny) return launch_qskinny<EPI>(a, stream);     // peeled tail / tiny batch: split-K
-    // cost model (as launch_h_tiled in gemm_bf16.hip): rounds of 256 workgroups x tile area / relative tile efficiency
-    struct Cand { int bm, bn, id; double eff; };
-    const Cand cands[3] = {{256, 256, 0, 1.0}, {256, 128, 1, 0.7}, {128, 128, 2, 0.5}};
-    double best = -1.0;
-    int pick = 2;
-    for (const Cand &c : cands) {
-        const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
-        const double cost = (double)((tiles + 255) / 256) * c.bm * c.bn / c.eff;
-        if (best < 0 || cost < best) { best = cost; pick = c.id; }
-    }
+    // Time model fitted to scripts/gemm_fp8_bench.py on ViT-B / ViT-L shapes, M = 3 k .. 25 k (profiles/README.md), in us:
+    //   256 x 256 (one workgroup per CU):  strict rounds of 256 tiles, each  a[epi] + 11.3e-3 K
+    //   128 x 128 (two per CU, they overlap each other's prologue / epilogue):  rounds of 256 tiles, each  r[epi] + 4.25e-3 K,
+    //   but never less than one tile's own latency  5.3 + 8e-3 K.   (256 x 128 never won a shape: kept for experiments only.)
+    const double a256[3] = {14.3, 16.8, 21.3}, r128[3] = {3.65, 3.85, 7.2};
+    const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const double c256 = (double)((t256 + 255) / 256) * (a256[EPI] + 11.3e-3 * a.K);
+    double c128 = (double)((t128 + 255) / 256) * (r128[EPI] + 4.25e-3 * a.K);
+    if (c128 < 5.3 + 8e-3 * a.K) c128 = 5.3 + 8e-3 * a.K;
+    int pick = c256 <= c128 ? 0 : 2;
     if (const char *force = getenv("LDIT_GEMM_FP8_TILE"))
         if (force[0] >= '0' && force[0] <= '2' && force[1] == 0) pick = force[0] - '0';
     if (k16) {

@@ -42,12 +42,15 @@ __device__ __forceinline__ void glds16p(const float *gsrc, char *lds_wave_base)
 }
 
 
-// One float4 of the output: row m, columns n..n+3.  VEC: 16-B accesses, no bounds checks (block inside the matrix,
-// ldy % 4 == 0); otherwise element-wise with checks.  `res` = residual values already fetched (EPI_SCALE_RESID).
-template <int EPI, bool VEC, bool DUAL>
+// One float4 of the output: row m, columns n..n+3.  MODE 1: 16-B accesses, no bounds checks (block inside the matrix,
+// ldy % 4 == 0); MODE 2: 16-B accesses behind a row check (the ragged last row panel: columns inside, rows past M
+// skipped - the element-wise path costs ~20 us there because a lane owns a row, so its 4-byte accesses do not coalesce);
+// MODE 0: element-wise with checks.  `res` = residual values already fetched (EPI_SCALE_RESID).
+template <int EPI, int MODE, bool DUAL>
 __device__ __forceinline__ void emit4(const GemmArgs &p, int m, int n, f32x4 acc, f32x4 bias, f32x4 lam, f32x4 res)
 {
-    if (!VEC && m >= p.M) return;
+    constexpr bool VEC = MODE != 0;
+    if (MODE != 1 && m >= p.M) return;
     unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
     f32x4 pos = {0.f, 0.f, 0.f, 0.f};
     if (EPI == EPI_EMBED) {
@@ -81,11 +84,12 @@ __device__ __forceinline__ void emit4(const GemmArgs &p, int m, int n, f32x4 acc
     }
 }
 
-template <bool VEC>
+template <int MODE>
 __device__ __forceinline__ f32x4 load4(const GemmArgs &p, const float *base, int m, int n, bool row_major_out)
 {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (VEC) return *reinterpret_cast<const f32x4 *>(base + ((unsigned)m * (unsigned)p.ldy + (unsigned)n));
+    if (MODE == 1 || (MODE == 2 && m < p.M)) return *reinterpret_cast<const f32x4 *>(base + ((unsigned)m * (unsigned)p.ldy + (unsigned)n));
+    if (MODE == 2) return v;
     if (m < p.M)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -94,12 +98,12 @@ __device__ __forceinline__ f32x4 load4(const GemmArgs &p, const float *base, int
     return v;
 }
 
-template <bool VEC>
+template <int MODE>
 __device__ __forceinline__ f32x4 vec4(const float *v, int n, int N)
 {
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if (!v) return o;
-    if (VEC) return *reinterpret_cast<const f32x4 *>(v + n);
+    if (MODE != 0) return *reinterpret_cast<const f32x4 *>(v + n);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (n + r < N) o[r] = v[n + r];
@@ -110,7 +114,7 @@ __device__ __forceinline__ f32x4 vec4(const float *v, int n, int N)
 // nw + 8g + 4h .. +3.  16-row remainder, lane (c = lane&15, q = lane>>4): row m0+32*T32+c, tile it holds nw+16it+4q..+3.
 // The residual quads of the next tile are fetched before the current tile is stored (R may alias Y: fenced so that
 // hipcc neither hoists all loads to the top nor serialises them - see gemm_f32.hip).
-template <int T32, bool HALF, int EPI, bool VEC, bool DUAL>
+template <int T32, bool HALF, int EPI, int VEC, bool DUAL>
 __device__ __forceinline__ void store_panel(const GemmArgs &p, const f32x16 (&acc32)[T32], const f32x4 (&acc16)[2], int m0,
                                             int nw, int lane)
 {
@@ -348,14 +352,17 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
     st_clk2 = __builtin_amdgcn_s_memtime();
 #endif
     // ---- epilogue ---------------------------------------------------------------------------------------------------
-    const bool vec = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldy & 3) == 0);   // block-uniform
+    const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);                    // block-uniform
     const int nw = n0 + wave * 32;
-    if (vec) {
-        if (p.Y2) store_panel<T32, HALF, EPI, true, true>(p, acc32, acc16, m0, nw, lane);
-        else store_panel<T32, HALF, EPI, true, false>(p, acc32, acc16, m0, nw, lane);
+    if (cols_in && m0 + BM <= p.M) {
+        if (p.Y2) store_panel<T32, HALF, EPI, 1, true>(p, acc32, acc16, m0, nw, lane);
+        else store_panel<T32, HALF, EPI, 1, false>(p, acc32, acc16, m0, nw, lane);
+    } else if (cols_in) {
+        if (p.Y2) store_panel<T32, HALF, EPI, 2, true>(p, acc32, acc16, m0, nw, lane);
+        else store_panel<T32, HALF, EPI, 2, false>(p, acc32, acc16, m0, nw, lane);
     } else {
-        if (p.Y2) store_panel<T32, HALF, EPI, false, true>(p, acc32, acc16, m0, nw, lane);
-        else store_panel<T32, HALF, EPI, false, false>(p, acc32, acc16, m0, nw, lane);
+        if (p.Y2) store_panel<T32, HALF, EPI, 0, true>(p, acc32, acc16, m0, nw, lane);
+        else store_panel<T32, HALF, EPI, 0, false>(p, acc32, acc16, m0, nw, lane);
     }
 #ifdef LDIT_GEMM_STAMPS
     if (p.stamps) {

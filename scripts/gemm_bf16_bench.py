@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from layoutdit_amd import _lib, ops  # noqa: E402
 M = int(os.environ.get("M", 16 * 1025))
-C, F = 1024, 4096
+C = int(os.environ.get("C", 1024)); F = 4 * C
 tot_f = tot_t = 0.0
 for name, n, k, epi in (("qkv", 3 * C, C, _lib.EPI_BIAS), ("o_proj", C, C, _lib.EPI_SCALE_RESID), ("fc1", F, C, _lib.EPI_BIAS_GELU), ("fc2", C, F, _lib.EPI_SCALE_RESID)):
     x = torch.randn(M, k, device="cuda").to(torch.bfloat16); w = (torch.randn(n, k, device="cuda") * 0.05).to(torch.bfloat16)
