@@ -1,16 +1,26 @@
 // Fused multi-head self-attention, bf16 MFMA, fp32 softmax:  O = softmax(Q K^T * scale) V  per (image, head), no mask.
-// Q, K, V: bf16 column slices of the fused [B*N, 3C] projection; O: bf16 [B*N, C].  D = 64, any N (flash-style chunks of
-// 256 keys with the online-softmax rescale; N = 1025 for ViT-L at 512x512 is 5 chunks).
+// Q, K, V: bf16 column slices of the fused [B*N, 3C] projection; O: bf16 [B*N, C] (or fp8 codes).  D = 64, any N
+// (flash-style chunks of 64 keys with the online-softmax rescale; N = 1025 for ViT-L at 512x512 is 17 chunks).
 //
 // Same transposed formulation as attention_f32.hip, on v_mfma_f32_32x32x16_bf16:
 //   S^T[key][query] = K . Q^T     A = K fragment (LDS b128: 8 consecutive d of one key), B = Q^T fragment (registers)
-//   O^T[d][query]   = V^T . P^T   A = V^T fragment (LDS b128: 8 keys of one d),        B = P^T = the S^T accumulator
+//   O^T[d][query]   = V^T . P^T   A = V^T fragment (two ds_read_b64_tr_b16: 4 + 4 keys of one d), B = P^T = the S^T accumulator
 // A lane (query j, half h) of an S^T tile holds, in registers 8s..8s+7, the keys 16s + 8(jj>>2) + 4h + (jj&3) - packed
 // pairwise to bf16 they ARE the B-operand fragment of k-step s of the second product, provided the A operand uses the
-// same key order.  V^T is therefore parked in LDS with the keys of each 32-key tile permuted to
-// position 16s + 8h + 4(jj>>2) + (jj&3): one b128 read per lane and step, no shuffles, P never touches LDS.
-// Softmax (scale, running max, exp, running sum) is fp32 and lane-local apart from one lane<->lane+32 exchange.
+// same key order: the transposing LDS read delivers exactly that (rows = 4 consecutive keys starting at 16s + 8u + 4h,
+// columns = the 16 d of the lane group), so V stays key-major in LDS, P never touches LDS and nothing is shuffled.
+// K and V chunks are staged by LDS-DMA (global_load_lds, no registers, no scatter writes) into a double buffer: chunk
+// c+1 flies while chunk c is multiplied.  K image: 128-B rows, 16-B chunk XOR-swizzled with (row>>1)&7 (conflict-free
+// b128 reads); V image: 256-B blocks [4 keys][32 d] - one transposing read of a 32-lane half is exactly one block, i.e.
+// one full sweep of the 64 banks.  Rows past N are clamped duplicates of the last key and masked to -inf.
+// Softmax runs on raw scores in the exp2 domain (p = exp2(s c - m c), c = scale log2 e: one FMA + one v_exp_f32 per
+// element), fp32, lane-local apart from one lane<->lane+32 exchange.  Four waves (128 queries) per workgroup, 32 KB of
+// LDS and 128 VGPRs: four workgroups per CU, so on every SIMD one wave's softmax VALU work overlaps another's MFMAs.
+#include <cstdlib>
+
 #include "ldit_common.h"
+
+#define LDIT_TRY_RC(expr) do { int rc__ = (expr); if (rc__ != LDIT_OK) return rc__; } while (0)
 
 namespace ldit {
 
@@ -19,21 +29,27 @@ namespace {
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int KROWB = 128;            // bytes per K row in LDS (64 bf16), chunk-swizzled like the GEMM tiles
-constexpr int VPAD = 8;               // bf16 of padding per V^T row: 528-B stride -> conflict-free b128 reads over d
+constexpr int KROWB = 128;            // bytes per K row in LDS (64 bf16)
+
+__device__ __forceinline__ void glds16a(const void *gsrc, char *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
 
 // OUT_FP8: O is written as fp8 e4m3 codes of o / *qscale (operand of the fp8 o_proj GEMM), ldo in elements.
 template <int KT, int NW, bool OUT_FP8>
-__global__ void __launch_bounds__(NW * 64, NW / 4) attention_bf16(const bf16_t *__restrict__ Q, const bf16_t *__restrict__ K,
-                                                                  const bf16_t *__restrict__ V, void *__restrict__ Ov,
-                                                                  int N, int H, int ldq, int ldk, int ldv, int ldo,
-                                                                  float scale, int nqg, const float *__restrict__ qscale)
+__global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const bf16_t *__restrict__ Q, const bf16_t *__restrict__ K,
+                                                             const bf16_t *__restrict__ V, void *__restrict__ Ov,
+                                                             int N, int H, int ldq, int ldk, int ldv, int ldo,
+                                                             float scale, int nqg, const float *__restrict__ qscale)
 {
-    constexpr int KC = KT * 32, VSTR = KC + VPAD;     // keys per chunk; V^T row stride in bf16
+    constexpr int KC = KT * 32, HALF = KC * KROWB, STAGE = 2 * HALF;     // keys per chunk; K image, then V image
+    constexpr int PIECES = KC / 8, PPW = PIECES / NW;                    // 1-KB DMA pieces (8 keys) per operand, per wave
+    static_assert(PIECES % NW == 0, "DMA pieces must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *Ks = smem;                                   // [KC][64] bf16, swizzled 16-B chunks
-    bf16_t *Vt = reinterpret_cast<bf16_t *>(smem + KC * KROWB);   // [64][VSTR] bf16, keys permuted per 32-tile
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -52,105 +68,153 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attention_bf16(const bf16_t *
         const bf16_t *qp = Q + (tok0 + qrow) * ldq + head * 64 + 8 * h;
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s);
+        // retire these loads HERE: left pending, hipcc guards their first use inside the chunk loop with s_waitcnt vmcnt(0),
+        // which would also drain the DMA of the next chunk on every iteration
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
     }
+
+    // DMA source geometry of this lane.  K piece: 8 keys x 128 B, lane -> key lane>>3, source chunk (lane&7) ^ swizzle.
+    // V piece: 8 keys x 128 B as four 256-B blocks [4 keys][32 d]: lane -> block lane>>4 (key group (lane>>5), d half
+    // (lane>>4)&1), key (lane&15)>>2 of the group, 16-B piece lane&3 of the 64-B half row.
+    const int kkey = lane >> 3, vkey = 4 * (lane >> 5) + ((lane & 15) >> 2);
+    const int vd = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+    const bf16_t *Kh = K + tok0 * ldk + head * 64, *Vh = V + tok0 * ldv + head * 64;
+    auto issue = [&](int stage, int c0) {
+        char *kb = smem + stage * STAGE, *vb = kb + HALF;
+#pragma unroll
+        for (int u = 0; u < PPW; ++u) {
+            const int piece = wave + NW * u;
+            const int krow = 8 * piece + kkey;
+            int key = c0 + krow;
+            key = key < N ? key : N - 1;
+            glds16a(Kh + (size_t)key * ldk + 8 * ((lane & 7) ^ ((krow >> 1) & 7)), kb + piece * 1024);
+            int vk = c0 + 8 * piece + vkey;
+            vk = vk < N ? vk : N - 1;
+            glds16a(Vh + (size_t)vk * ldv + vd, vb + piece * 1024);
+        }
+    };
 
     f32x16 o[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { o[0][e] = 0.0f; o[1][e] = 0.0f; }
     float m_run = -INFINITY, l_run = 0.0f;
+    const float c = scale * 1.44269504088896340736f;     // softmax in the exp2 domain
     const int sw = (c32 >> 1) & 7;
+    // transposing read: lane 4q+p of a 16-lane group addresses key q, d 4p..4p+3 of the group's 16 columns
+    const int vlane = 64 * ((lane & 15) >> 2) + 32 * ((lane >> 4) & 1) + 8 * (lane & 3) + 512 * h;
 
-    for (int c0 = 0; c0 < N; c0 += KC) {
+    const int nchunks = (N + KC - 1) / KC;
+    issue(0, 0);
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int c0 = ci * KC;
         const int nkeys = (N - c0) < KC ? (N - c0) : KC;
         const int ktiles = (nkeys + 31) >> 5;
-        if (c0) __syncthreads();
-        // ---- stage K (row-major, swizzled) and V^T (transposed, keys permuted); rows past N are zeros -------------------
-        for (int u = tid; u < ktiles * 32 * 8; u += NW * 64) {
-            const int row = u >> 3, c = u & 7;
-            bf16x8 kv, vv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { kv[e] = (bf16_t)0.0f; vv[e] = (bf16_t)0.0f; }
-            if (row < nkeys) {
-                kv = *reinterpret_cast<const bf16x8 *>(K + (tok0 + c0 + row) * ldk + head * 64 + 8 * c);
-                vv = *reinterpret_cast<const bf16x8 *>(V + (tok0 + c0 + row) * ldv + head * 64 + 8 * c);
-            }
-            *reinterpret_cast<bf16x8 *>(Ks + row * KROWB + ((c ^ ((row >> 1) & 7)) * 16)) = kv;
-            // key = 32 kt + 16 s + 8 a + 4 hh + bb  ->  position 32 kt + 16 s + 8 hh + 4 a + bb
-            const int k5 = row & 31, pos = (row & ~31) | (k5 & 16) | ((k5 & 4) << 1) | ((k5 & 8) >> 1) | (k5 & 3);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) Vt[(8 * c + e) * VSTR + pos] = vv[e];
+        if (ci + 1 < nchunks) {
+            issue((ci + 1) & 1, c0 + KC);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");   // chunk ci landed, ci+1 flies
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __syncthreads();
-        if (!active) continue;
-
-        // ---- S^T = K . Q^T ---------------------------------------------------------------------------------------------
-        f32x16 s[KT];
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (active) {
+            const char *Ks = smem + (ci & 1) * STAGE;
+            const char *Vs = Ks + HALF;
+            // ---- S^T = K . Q^T -------------------------------------------------------------------------------------
+            f32x16 s[KT];
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
+            for (int kt = 0; kt < KT; ++kt) {
+                s[kt] = zero16;
+                if (kt < ktiles) {
+                    const char *kr = Ks + (kt * 32 + c32) * KROWB;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[kt][e] = 0.0f;
-            if (kt < ktiles) {
-                const char *kr = Ks + (kt * 32 + c32) * KROWB;
+                    for (int st = 0; st < 4; ++st) {
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kr + (((2 * st + h) ^ sw) * 16));
+                        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], st ? s[kt] : zero16, 0, 0, 0);
+                    }
+                }
+            }
+            // ---- mask padded keys (last chunk only: a real branch, not 2 VALU ops on every score), running max on the raw
+            //      scores (scale > 0 commutes with max) ---------------------------------------------------------------------
+            if (nkeys < KC) {
 #pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kr + (((2 * st + h) ^ sw) * 16));
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[kt], 0, 0, 0);
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if ((kt * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) >= nkeys) s[kt][r] = -INFINITY;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                if (kt < ktiles) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            const float mc = m_new * c;
+            m_run = m_new;
+            float lsum = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                if (kt < ktiles) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c, -mc));
+                        s[kt][r] = pv;
+                        lsum += pv;
+                    }
+                }
+            }
+            l_run = l_run * alpha + lsum;
+            if (ci) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+            }
+            // ---- O^T += V^T . P^T ---------------------------------------------------------------------------------------
+            // The transposing reads are inline asm: through the builtin, hipcc cannot tell that they do not alias the
+            // LDS-DMA writes of the NEXT chunk and guards each group with s_waitcnt vmcnt(0), which would serialise the
+            // double buffer.  Asm reads are invisible to the compiler's waitcnt pass, hence the explicit lgkmcnt(0) and
+            // the sched_barrier that keeps the MFMAs below it.
+            const unsigned vaddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) const char *)(Vs + vlane));
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                if (kt < ktiles) {
+                    // block (key group, d half) = ((32 kt + 16 st + 8 u + 4 h) / 4) * 2 + dt; h is in vlane
+                    s16x4 vr[2][2][2];                 // [st][dt][u]
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+                                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"
+                                             : "=v"(vr[st][dt][u])
+                                             : "v"(vaddr), "n"((16 * kt + 8 * st + 4 * u + dt) * 256));
+                    bf16x8 pf[2];
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) pf[st][jj] = (bf16_t)s[kt][8 * st + jj];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            union { s16x4 v[2]; bf16x8 f; } vf;
+                            vf.v[0] = vr[st][dt][0]; vf.v[1] = vr[st][dt][1];
+                            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.f, pf[st], o[dt], 0, 0, 0);
+                        }
                 }
             }
         }
-        // ---- scale, mask padded keys, running max --------------------------------------------------------------------------
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            if (kt < ktiles) {
-                const bool partial = (kt + 1) * 32 > nkeys;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = s[kt][r] * scale;
-                    if (partial && (kt * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) >= nkeys) v = -INFINITY;
-                    s[kt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
-        m_run = m_new;
-        float lsum = 0.0f;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            if (kt < ktiles) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __expf(s[kt][r] - m_new);
-                    s[kt][r] = pv;
-                    lsum += pv;
-                }
-            }
-        }
-        l_run = l_run * alpha + lsum;
-        if (c0) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
-        }
-        // ---- O^T += V^T . P^T -------------------------------------------------------------------------------------------------
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            if (kt < ktiles) {
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    bf16x8 pf;
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)s[kt][8 * st + jj];
-                    const bf16_t *vr = Vt + c32 * VSTR + kt * 32 + 16 * st + 8 * h;
-                    const bf16x8 v0 = *reinterpret_cast<const bf16x8 *>(vr);
-                    const bf16x8 v1 = *reinterpret_cast<const bf16x8 *>(vr + 32 * VSTR);
-                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf, o[0], 0, 0, 0);
-                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf, o[1], 0, 0, 0);
-                }
-            }
-        }
+        __builtin_amdgcn_s_barrier();                  // every wave is done with this stage before chunk ci+2 overwrites it
+        asm volatile("" ::: "memory");
     }
 
     if (!active) return;
@@ -192,19 +256,24 @@ static int launch_attn(const void *Q, const void *K, const void *V, void *O, int
     if ((ldq | ldk | ldv) & 7 || (ldo & 3)) return fail(LDIT_EINVAL, "attention_bf16: row strides must be multiples of 8 (in) / 4 (out)");
     if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || (reinterpret_cast<uintptr_t>(O) & (OUT_FP8 ? 3u : 7u)))
         return fail(LDIT_EINVAL, "attention_bf16: operands must be 16-byte aligned");
-    constexpr int KT = 8, NW = 8;
-    constexpr int lds = KT * 32 * KROWB + 64 * (KT * 32 + VPAD) * 2;
+    static const bool kt4 = [] { const char *e = getenv("LDIT_ATTN_BF16_KT"); return e && *e == '4'; }();
+    constexpr int NW = 4;
     const int nqt = (N + 31) / 32, nqg = (nqt + NW - 1) / NW;
-    auto kern = attention_bf16<KT, NW, OUT_FP8>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(B * H * nqg)), dim3(NW * 64), lds, stream, static_cast<const bf16_t *>(Q),
-                       static_cast<const bf16_t *>(K), static_cast<const bf16_t *>(V), O, N, H, ldq, ldk, ldv, ldo, scale, nqg,
-                       qscale);
+    auto go = [&](auto kern, int lds, bool &attr_set) -> int {
+        if (!attr_set) {
+            LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)(B * H * nqg)), dim3(NW * 64), lds, stream, static_cast<const bf16_t *>(Q),
+                           static_cast<const bf16_t *>(K), static_cast<const bf16_t *>(V), O, N, H, ldq, ldk, ldv, ldo, scale, nqg,
+                           qscale);
+        return LDIT_OK;
+    };
+    // LDS = two stages of (K image + V image).  64-key chunks: 32 KB and 128 VGPRs -> four workgroups per CU (four waves per
+    // SIMD), measured 8-10 % faster than 128-key chunks at two per CU (LDIT_ATTN_BF16_KT=4) on N = 197 and N = 1025.
+    static bool set2 = false, set4 = false;
+    if (kt4) LDIT_TRY_RC(go(attention_bf16<4, NW, OUT_FP8>, 2 * 2 * 4 * 32 * KROWB, set4));
+    else LDIT_TRY_RC(go(attention_bf16<2, NW, OUT_FP8>, 2 * 2 * 2 * 32 * KROWB, set2));
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }

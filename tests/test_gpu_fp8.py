@@ -173,3 +173,38 @@ def test_fp8_forward_base_vs_fp32_build_and_batch_invariance():
         assert rel_l2(a, b) < 1e-1, t
         assert _cos(a, b) > 0.995, t
         assert torch.equal(got[t][5:7], part[t]), t
+
+
+def test_fp8_forward_ragged_rectangular_and_graph_replay():
+    """Odd batch, non-square grid (resampled position table) and hipGraph capture of the fp8 build."""
+    from layoutdit_amd import config as cfgs
+    from layoutdit_amd.modeling import DiTEncoder
+    from tests.util import resample_pos
+    cfg = cfgs.vit_micro()
+    w = synth.synth_weights(cfg, 9)
+    x = synth.synth_images(3, 96, 64, seed=31)                    # 6 x 4 grid, 25 tokens, M = 75 rows
+    m = DiTEncoder(cfg, compute_dtype="fp8").load_numpy(w).to(DEV).eval()
+    xd = torch.from_numpy(x).to(DEV)
+    m.calibrate_fp8(xd)
+    with torch.no_grad():
+        hs = m(xd).hidden_states
+    eager = [h.clone() for h in hs if h is not None]
+    pos = resample_pos(w["embeddings.position_embeddings"], 4, 6, 4)
+    _, hidden = oracle.vit_forward(cfg, w, x, pos=pos, all_hidden=True)
+    for t in sorted(set(cfg.taps)):
+        a = hs[t].cpu().numpy()
+        assert rel_l2(a, hidden[t]) < 1e-1 and _cos(a, hidden[t]) > 0.995, t
+    static_x = xd.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.no_grad():
+        with torch.cuda.stream(s):
+            m(static_x)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = [h for h in m(static_x).hidden_states if h is not None]
+        graph.replay()
+        torch.cuda.synchronize()
+    for a, b in zip(static_out, eager):
+        assert torch.equal(a, b)
