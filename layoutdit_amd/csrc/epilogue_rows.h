@@ -1,0 +1,87 @@
+// Row-contiguous epilogue for the swapped-operand MFMA GEMMs (gemm_bf16.hip, gemm_fp8.hip).
+//
+// In those kernels an accumulator tile has the output ROW on the lane (acc[i][j][4g+e] = row 32i + (lane&31), column
+// 32j + 8g + 4(lane>>5) + e), so storing straight from the registers makes every store instruction touch 64 different
+// rows with 8 or 16 bytes each - the epilogue becomes store-issue bound (it measured ~25 k cycles per 256 x 256 bf16 tile,
+// as long as half a K = 1024 main loop).  Here each wave passes its 32-row x 64-column slabs through a private LDS
+// buffer (the k-loop's stage memory, free by then) and writes them back row-major: 16 lanes cover one 64-column row
+// segment, so every global access is a full contiguous 64 ... 256-byte run, and the residual is read the same way.
+#pragma once
+
+#include "ldit_common.h"
+
+namespace ldit {
+
+typedef __bf16 epi_bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int EPI_ROW_BYTES = 272;                    // 64 fp32 + 16 B pad: 68 dwords -> b128 writes of 8 lanes hit 32 banks once
+constexpr int EPI_WAVE_BYTES = 32 * EPI_ROW_BYTES;    // one 32 x 64 slab per wave
+
+enum { EPI_OUT_BF16 = 0, EPI_OUT_FP8 = 1, EPI_OUT_F32 = 2 };
+
+// acc: the wave's TM x TN tiles; (mw, nw): its first row / column; buf: EPI_WAVE_BYTES of LDS private to this wave.
+// t = fma(acc, ab, bias) ; GELU ; (resid: fma(lam, t, R)) ; bf16 / fp8 (times oinv, saturating) / fp32 (+ copy to Y2).
+// The arithmetic is spelled with explicit fmas, identically to the direct stores of the ragged tiles, so that a row gets
+// the same bits whichever path its tile takes (batch invariance of the bf16 / fp8 builds).
+template <int TM, int TN, int EPI, int OUT>
+__device__ __forceinline__ void store_rows_via_lds(const f32x16 (&acc)[TM][TN], char *buf, void *Yv, float *Y2, const float *R,
+                                                   const float *bias, const float *lam, int ldy, int mw, int nw, int lane,
+                                                   float ab, float oinv)
+{
+    static_assert(TN % 2 == 0, "slabs are 64 columns wide");
+    const int c32 = lane & 31, h = lane >> 5;
+    const int rrow = lane >> 4, rq = lane & 15;       // read-back: 4 rows per pass, 16 lanes x 4 columns per row
+#pragma unroll
+    for (int jp = 0; jp < TN / 2; ++jp) {
+        f32x4 bq[2][4];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nw + 64 * jp + 32 * jj + 8 * g + 4 * h;
+                bq[jj][g] = bias ? *reinterpret_cast<const f32x4 *>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        const f32x4 lamq = EPI == EPI_SCALE_RESID ? *reinterpret_cast<const f32x4 *>(lam + nw + 64 * jp + 4 * rq)
+                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = __builtin_fmaf(acc[i][2 * jp + jj][4 * g + e], ab, bq[jj][g][e]);
+                        if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
+                        v[e] = t;
+                    }
+                    *reinterpret_cast<f32x4 *>(buf + c32 * EPI_ROW_BYTES + (32 * jj + 8 * g + 4 * h) * 4) = v;
+                }
+            const unsigned n = (unsigned)(nw + 64 * jp + 4 * rq);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int row = 4 * r + rrow;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(buf + row * EPI_ROW_BYTES + rq * 16);
+                const unsigned o = (unsigned)(mw + 32 * i + row) * (unsigned)ldy + n;
+                if (OUT == EPI_OUT_F32) {
+                    if (EPI == EPI_SCALE_RESID) {
+                        const f32x4 res = *reinterpret_cast<const f32x4 *>(R + o);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(lamq[e], v[e], res[e]);
+                    }
+                    *reinterpret_cast<f32x4 *>(static_cast<float *>(Yv) + o) = v;
+                    if (Y2) *reinterpret_cast<f32x4 *>(Y2 + o) = v;
+                } else if (OUT == EPI_OUT_FP8) {
+                    *reinterpret_cast<unsigned *>(static_cast<unsigned char *>(Yv) + o) =
+                        pack_fp8x4(v[0] * oinv, v[1] * oinv, v[2] * oinv, v[3] * oinv);
+                } else {
+                    const epi_bf16x4 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *reinterpret_cast<epi_bf16x4 *>(static_cast<__bf16 *>(Yv) + o) = pk;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace ldit

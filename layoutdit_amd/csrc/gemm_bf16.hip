@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "ldit_common.h"
+#include "epilogue_rows.h"
 
 namespace ldit {
 
@@ -43,6 +44,7 @@ struct GemmArgsH {
     const float *lam;    // [N] fp32
     const float *R;      // [M, N] fp32, may alias Y
     int M, N, K, lda, ldy;
+    int direct_epi;      // LDIT_GEMM_DIRECT_EPILOGUE=1: interior tiles stored straight from the accumulators (A/B experiments)
 };
 
 // MODE 0: tile inside the matrix, 16-B / 8-B accesses unchecked; MODE 1: columns inside, rows past M skipped (the ragged
@@ -91,7 +93,7 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
                 for (int e = 0; e < 4; ++e) {
                     float t = acc[i][j][4 * g + e] + bias[g][e];
                     if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
-                    if (EPI == EPI_SCALE_RESID) t = res[g][e] + lam[g][e] * t;
+                    if (EPI == EPI_SCALE_RESID) t = __builtin_fmaf(lam[g][e], t, res[g][e]);
                     v[e] = t;
                 }
                 if (EPI == EPI_SCALE_RESID) {
@@ -288,7 +290,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
 
     const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
-    if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
+    if (cols_in && m0 + BM <= p.M && !p.direct_epi) {
+        __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
+        store_rows_via_lds<TM, TN, EPI, EPI == EPI_SCALE_RESID ? EPI_OUT_F32 : EPI_OUT_BF16>(
+            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, p.ldy, mw, nw, lane, 1.0f, 1.0f);
+    } else if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
     else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
     else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
 }
@@ -413,7 +419,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) gemm_bf16_ring(co
 
     const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
-    if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
+    if (cols_in && m0 + BM <= p.M && !p.direct_epi) {
+        __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
+        store_rows_via_lds<TM, TN, EPI, EPI == EPI_SCALE_RESID ? EPI_OUT_F32 : EPI_OUT_BF16>(
+            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, p.ldy, mw, nw, lane, 1.0f, 1.0f);
+    } else if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
     else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
     else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
 }
@@ -554,7 +564,11 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_pp(const GemmArgsH p)
 
     const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
-    if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
+    if (cols_in && m0 + BM <= p.M && !p.direct_epi) {
+        __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
+        store_rows_via_lds<TM, TN, EPI, EPI == EPI_SCALE_RESID ? EPI_OUT_F32 : EPI_OUT_BF16>(
+            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, p.ldy, mw, nw, lane, 1.0f, 1.0f);
+    } else if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
     else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
     else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
 }
@@ -652,7 +666,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_skinny(const GemmArgsH p)
         const size_t o = (size_t)row * p.ldy + n;
         if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
         if (EPI == EPI_SCALE_RESID) {
-            t = p.R[o] + p.lam[n] * t;
+            t = __builtin_fmaf(p.lam[n], t, p.R[o]);
             static_cast<float *>(p.Y)[o] = t;
             if (p.Y2) p.Y2[o] = t;
         } else {
@@ -757,6 +771,8 @@ static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const flo
     GemmArgsH a{};
     a.A = static_cast<const bf16_t *>(A); a.W = static_cast<const bf16_t *>(W); a.Y = Y; a.Y2 = Y2; a.bias = bias; a.lam = lam;
     a.R = R; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldy = ldy;
+    static const int direct = [] { const char *e = getenv("LDIT_GEMM_DIRECT_EPILOGUE"); return (e && *e == '1') ? 1 : 0; }();
+    a.direct_epi = direct;
     switch (epi) {
         case EPI_BIAS: return launch_h_tiled<EPI_BIAS>(a, stream);
         case EPI_BIAS_GELU: return launch_h_tiled<EPI_BIAS_GELU>(a, stream);

@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "ldit_common.h"
+#include "epilogue_rows.h"
 
 namespace ldit {
 
@@ -36,6 +37,7 @@ struct GemmArgs8 {
     float ab_scale;               // sa * sw: dequantisation of the accumulator
     float out_inv_scale;          // 1 / scale of the fp8 output (BIAS_GELU)
     const float *d_ab, *d_out;    // device-resident {sa, sw} / {so}: override the two host values when non-null
+    int direct_epi;               // LDIT_GEMM_DIRECT_EPILOGUE=1: interior tiles stored straight from the accumulators
 };
 
 // MODE 0: tile inside the matrix, 16-B / 8-B accesses unchecked; MODE 1: columns inside, rows past M skipped (the ragged
@@ -84,9 +86,9 @@ __device__ __forceinline__ void store_q(const GemmArgs8 &p, const f32x16 (&acc)[
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = acc[i][j][4 * g + e] * ab + bias[g][e];
+                    float t = __builtin_fmaf(acc[i][j][4 * g + e], ab, bias[g][e]);
                     if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
-                    if (EPI == EPI_SCALE_RESID) t = res[g][e] + lam[g][e] * t;
+                    if (EPI == EPI_SCALE_RESID) t = __builtin_fmaf(lam[g][e], t, res[g][e]);
                     v[e] = t;
                 }
                 if (EPI == EPI_SCALE_RESID) {
@@ -263,7 +265,13 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_fp8_mfma(con
 
     const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
-    if (cols_in && m0 + BM <= p.M) store_q<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
+    if (cols_in && m0 + BM <= p.M && !p.direct_epi) {
+        __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
+        const float ab = p.d_ab ? p.d_ab[0] * p.d_ab[1] : p.ab_scale;
+        const float oinv = (EPI == EPI_BIAS_GELU && p.d_out) ? 1.0f / p.d_out[0] : p.out_inv_scale;
+        store_rows_via_lds<TM, TN, EPI, EPI == EPI_SCALE_RESID ? EPI_OUT_F32 : EPI == EPI_BIAS_GELU ? EPI_OUT_FP8 : EPI_OUT_BF16>(
+            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, p.ldy, mw, nw, lane, ab, oinv);
+    } else if (cols_in && m0 + BM <= p.M) store_q<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
     else if (cols_in) store_q<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
     else store_q<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
 }
@@ -355,12 +363,12 @@ __global__ void __launch_bounds__(512, 2) gemm_fp8_skinny(const GemmArgs8 p)
     for (int e = 0; e < 8; ++e) {
         const int n = n0 + col + e;
         if (n >= p.N) break;
-        float t = (e < 4 ? s0[e] : s1[e - 4]) * ab + (p.bias ? p.bias[n] : 0.0f);
+        float t = __builtin_fmaf(e < 4 ? s0[e] : s1[e - 4], ab, p.bias ? p.bias[n] : 0.0f);
         const size_t o = (size_t)row * p.ldy + n;
         if (EPI == EPI_BIAS_GELU) {
             static_cast<unsigned char *>(p.Y)[o] = (unsigned char)pack_fp8x4(gelu_erf(t) * oinv, 0.f, 0.f, 0.f);
         } else if (EPI == EPI_SCALE_RESID) {
-            t = p.R[o] + p.lam[n] * t;
+            t = __builtin_fmaf(p.lam[n], t, p.R[o]);
             static_cast<float *>(p.Y)[o] = t;
             if (p.Y2) p.Y2[o] = t;
         } else {
@@ -490,6 +498,8 @@ static int launch_gemm_fp8_one(const void *A, int lda, const void *W, const floa
     a.A = static_cast<const unsigned char *>(A); a.W = static_cast<const unsigned char *>(W); a.Y = Y; a.Y2 = Y2;
     a.bias = bias; a.lam = lam; a.R = R; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldy = ldy;
     a.ab_scale = ab_scale; a.out_inv_scale = out_inv_scale; a.d_ab = d_ab; a.d_out = d_out;
+    static const int direct = [] { const char *e = getenv("LDIT_GEMM_DIRECT_EPILOGUE"); return (e && *e == '1') ? 1 : 0; }();
+    a.direct_epi = direct;
     switch (epi) {
         case EPI_BIAS: return launch_q_tiled<EPI_BIAS>(a, stream);
         case EPI_BIAS_GELU: return launch_q_tiled<EPI_BIAS_GELU>(a, stream);

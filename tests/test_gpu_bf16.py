@@ -154,3 +154,19 @@ def test_linear_bf16_skinny(M, N, K):
     ops.linear_bf16(xd, wd, bd, epilogue=_lib.EPI_SCALE_RESID, lam=torch.from_numpy(lam).to(DEV), residual=h, out=h)
     ref = (r.astype(np.float64) + lam.astype(np.float64) * oracle.linear(x, w, b).astype(np.float64)).astype(np.float32)
     assert rel_l2(h.cpu().numpy(), ref) < 1e-5
+
+
+def test_forward_bf16_is_batch_invariant():
+    """An image's taps do not depend on the batch it rides in: every dot product has a fixed k-order and the epilogues use
+    the same explicit fmas on the slab path (interior tiles) and on the direct path (ragged tiles), so bs=64 (M = 12608,
+    256 x 256 tiles) and bs=2 (M = 394, 128 x 128 tiles, ragged) agree bit for bit."""
+    from layoutdit_amd import config as cfgs
+    from layoutdit_amd.modeling import DiTEncoder
+    cfg = cfgs.vit_base()
+    m = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(synth.synth_weights(cfg, 0)).to(DEV).eval()
+    x = torch.from_numpy(synth.synth_images(64, 224, 224, seed=1234)).to(DEV)
+    with torch.no_grad():
+        big = m(x).hidden_states
+        small = m(x[40:42]).hidden_states
+    for t in cfg.taps:
+        assert torch.equal(big[t][40:42], small[t]), t
