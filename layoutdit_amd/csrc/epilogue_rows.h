@@ -53,7 +53,7 @@ __device__ __forceinline__ void store_rows_via_lds(const f32x16 (&acc)[TM][TN], 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float t = __builtin_fmaf(acc[i][2 * jp + jj][4 * g + e], ab, bq[jj][g][e]);
-                        if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
+                        if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
                         v[e] = t;
                     }
                     *reinterpret_cast<f32x4 *>(buf + c32 * EPI_ROW_BYTES + (32 * jj + 8 * g + 4 * h) * 4) = v;

@@ -92,7 +92,7 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float t = acc[i][j][4 * g + e] + bias[g][e];
-                    if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
+                    if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
                     if (EPI == EPI_SCALE_RESID) t = __builtin_fmaf(lam[g][e], t, res[g][e]);
                     v[e] = t;
                 }
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_skinny(const GemmArgsH p)
         if (n >= p.N) break;
         float t = (e < 4 ? s0[e] : s1[e - 4]) + (p.bias ? p.bias[n] : 0.0f);
         const size_t o = (size_t)row * p.ldy + n;
-        if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
+        if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
         if (EPI == EPI_SCALE_RESID) {
             t = __builtin_fmaf(p.lam[n], t, p.R[o]);
             static_cast<float *>(p.Y)[o] = t;

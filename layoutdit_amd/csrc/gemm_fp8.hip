@@ -87,7 +87,7 @@ __device__ __forceinline__ void store_q(const GemmArgs8 &p, const f32x16 (&acc)[
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float t = __builtin_fmaf(acc[i][j][4 * g + e], ab, bias[g][e]);
-                    if (EPI == EPI_BIAS_GELU) t = gelu_erf(t);
+                    if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
                     if (EPI == EPI_SCALE_RESID) t = __builtin_fmaf(lam[g][e], t, res[g][e]);
                     v[e] = t;
                 }
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(512, 2) gemm_fp8_skinny(const GemmArgs8 p)
         float t = __builtin_fmaf(e < 4 ? s0[e] : s1[e - 4], ab, p.bias ? p.bias[n] : 0.0f);
         const size_t o = (size_t)row * p.ldy + n;
         if (EPI == EPI_BIAS_GELU) {
-            static_cast<unsigned char *>(p.Y)[o] = (unsigned char)pack_fp8x4(gelu_erf(t) * oinv, 0.f, 0.f, 0.f);
+            static_cast<unsigned char *>(p.Y)[o] = (unsigned char)pack_fp8x4(gelu_erf_lp(t) * oinv, 0.f, 0.f, 0.f);
         } else if (EPI == EPI_SCALE_RESID) {
             t = __builtin_fmaf(p.lam[n], t, p.R[o]);
             static_cast<float *>(p.Y)[o] = t;

@@ -53,6 +53,21 @@ __device__ __forceinline__ float erf_fast(float a)
 // exact (erf) GELU of TF:activations.py:70-89
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f)); }
 
+// erf-GELU for results that are rounded to bf16 / fp8 right after (bf16 and fp8 builds): Abramowitz-Stegun 7.1.25,
+// erf(x) = 1 - (a1 t + a2 t^2 + a3 t^3) exp(-x^2), t = 1 / (1 + p x), |error| <= 2.5e-5, i.e. |gelu error| <= 1.3e-5 |v| -
+// two orders below the bf16 rounding step - in 10 plain VALU ops + v_rcp_f32 + v_exp_f32 (the <1 ulp erf_fast above costs
+// ~25 and made the fc1 epilogue as long as a third of its K = 768 main loop).  The fp32 build keeps gelu_erf.
+__device__ __forceinline__ float gelu_erf_lp(float v)
+{
+    const float x = __builtin_fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.47047f, x, 1.0f));
+    const float poly = t * __builtin_fmaf(t, __builtin_fmaf(t, 0.7478556f, -0.0958798f), 0.3480242f);
+    const float e = __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);
+    const float er = __builtin_copysignf(__builtin_fmaf(-poly, e, 1.0f), v);
+    const float hv = 0.5f * v;
+    return __builtin_fmaf(hv, er, hv);
+}
+
 // 4 floats -> 4 fp8 e4m3 (round to nearest even, saturating at +-448), packed little-endian in one dword
 __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d)
 {
