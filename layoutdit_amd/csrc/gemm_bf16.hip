@@ -699,7 +699,9 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
     //   256 x 256, 8 waves (one workgroup per CU):  strict rounds of 256 tiles, each  a[epi] + 19.5e-3 K
     //   128 x 128 (two per CU, they overlap each other's prologue / epilogue):  rounds of 256 tiles, each  r[epi] + 7.6e-3 K,
     //   but never less than one tile's own latency  5 + 11.4e-3 K.
-    // (256 x 128 and the ring / ping-pong variants never won a shape by more than a few percent: kept for experiments only.
+    // (256 x 128 and the ring / ping-pong variants never won a shape by more than a few percent: kept for experiments only;
+    //  a v_mfma_f32_16x16x32_bf16 build of this kernel - same LDS image, conflict-free for that lane map too - measured
+    //  equal to the 32x32x16 one on every shape, 432.6 vs 432.2 us per ViT-L layer, and was dropped.
     //  A 288 x 256 four-wave "panel" instantiation <1,4,9,2> fixes the tile quantisation at M = 16 x 1025 but needs the
     //  pinned DMA/read schedule of gemm_panel_f32.hip to pay off: naive it spills and ran 439 vs 599 TFLOP/s)
     const double a256[3] = {19.0, 18.5, 25.0}, r128[3] = {5.2, 5.0, 7.7};
