@@ -117,6 +117,35 @@ def test_state_dict_layouts_round_trip():
     assert set(remap_state_dict(saved)) == set(w)
 
 
+def test_low_precision_builds_keep_the_checkpoint_surface_and_size_their_buffers():
+    """bf16 / fp8 builds: same state_dict keys as fp32 (the fp8 activation scales are a non-persistent buffer), packed
+    block = 2-byte / 1-byte matrices (+ 8 scale floats per layer for fp8), fp8 geometry limits reported by the library."""
+    lib = _lib.load()
+    cfg = cfgs.vit_base()
+    keys = set(DiTEncoder(cfg).state_dict())
+    for dt in ("bf16", "fp8"):
+        m = DiTEncoder(cfg, compute_dtype=dt)
+        assert set(m.state_dict()) == keys
+    assert tuple(DiTEncoder(cfg, compute_dtype="fp8").fp8_act_scales.shape) == (12, _lib.FP8_A_COUNT)
+    with pytest.raises(ValueError, match="compute_dtype"):
+        DiTEncoder(cfg, compute_dtype="fp16")
+    mats = 12 * (3 * 768 * 768 + 768 * 768 + 2 * 768 * 3072)
+    lc = _cfg(cfg)
+    f32 = lib.ldit_packed_bytes(C.byref(lc))
+    lc.dtype = _lib.DTYPE_BF16
+    assert lib.ldit_packed_bytes(C.byref(lc)) == f32 - 2 * mats
+    lc.dtype = _lib.DTYPE_FP8
+    assert lib.ldit_packed_bytes(C.byref(lc)) == f32 - 3 * mats + 12 * 32
+    lt = _cfg(cfgs.vit_tiny())                       # hidden 192: not a multiple of the fp8 k-tile
+    lt.dtype = _lib.DTYPE_FP8
+    assert lib.ldit_packed_bytes(C.byref(lt)) == 0 and "multiples of 128" in lib.ldit_last_error().decode()
+    scales = (C.c_float * 48)(*([1.0] * 48))
+    assert lib.ldit_set_fp8_act_scales(C.byref(lc), None, 0, scales, None) == _lib.LDIT_EINVAL      # null packed block
+    lc.dtype = _lib.DTYPE_F32
+    assert lib.ldit_set_fp8_act_scales(C.byref(lc), C.c_void_p(16), 1 << 40, scales, None) == _lib.LDIT_EINVAL
+    assert "not LDIT_FP8" in lib.ldit_last_error().decode()
+
+
 def test_cpu_input_fails_loudly_instead_of_falling_back():
     m = DiTEncoder(cfgs.vit_micro())
     with pytest.raises(RuntimeError, match="no CPU"):

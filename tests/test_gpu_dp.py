@@ -1,0 +1,65 @@
+"""Data-parallel sharding on the GPU: two processes (gloo control plane, both on the box's one card) each run the
+encoder on their contiguous shard of a global batch; gathered back, the taps are BIT-IDENTICAL to one process running
+the whole batch - images never mix and the arithmetic does not depend on the batch an image rides in, so bench.py's
+N > 1 path (no data-path collective) computes exactly what N = 1 computes."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import torch.multiprocessing as mp          # noqa: E402
+
+from layoutdit_amd import config as cfgs, dp, synth     # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from layoutdit_amd.modeling import DiTEncoder
+    r = dp.init(backend="gloo")
+    try:
+        cfg = cfgs.vit_tiny()
+        m = DiTEncoder(cfg).load_numpy(synth.synth_weights(cfg, 0)).to("cuda:0").eval()
+        lo, hi = dp.shard_range(total, r.rank, r.world)
+        x = torch.from_numpy(synth.synth_images(hi - lo, 224, 224, seed=1234, first_index=lo)).to("cuda:0")
+        dp.barrier(r)
+        with torch.no_grad():
+            out = m(x).hidden_states
+        torch.cuda.synchronize()
+        n = dp.sum_over_ranks(r, float(hi - lo))
+        q.put((r.rank, lo, hi, n, {t: out[t].cpu().numpy() for t in cfg.taps}))
+    finally:
+        dp.finalize(r)
+
+
+def test_two_gpu_ranks_reproduce_the_unsharded_batch_bit_for_bit():
+    world, total, port = 2, 5, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [(g[1], g[2]) for g in got] == [(0, 3), (3, 5)] and all(g[3] == total for g in got)
+    from layoutdit_amd.modeling import DiTEncoder
+    cfg = cfgs.vit_tiny()
+    m = DiTEncoder(cfg).load_numpy(synth.synth_weights(cfg, 0)).to("cuda:0").eval()
+    with torch.no_grad():
+        full = m(torch.from_numpy(synth.synth_images(total, 224, 224, seed=1234)).to("cuda:0")).hidden_states
+    for t in cfg.taps:
+        ref = full[t].cpu().numpy()
+        np.testing.assert_array_equal(np.concatenate([g[4][t] for g in got]), ref)
