@@ -622,18 +622,32 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_skinny(const GemmArgsH p)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     const bf16_t *ap[2] = {p.A + (size_t)ra[0] * p.lda + k0 + 8 * h, p.A + (size_t)ra[1] * p.lda + k0 + 8 * h};
     const bf16_t *wp[2] = {p.W + (size_t)rw[0] * p.K + k0 + 8 * h, p.W + (size_t)rw[1] * p.K + k0 + 8 * h};
-    for (int s = 0; s < kslice / 16; ++s) {
-        bf16x8 xa[2], wb[2];
+    // Every wave streams its K slice straight from global memory; four steps of fragment loads are issued before the
+    // first of their MFMAs so that one memory latency covers four steps (the plain load-then-multiply loop was latency
+    // bound: 24 us for the 16-row tail of fc2 at K = 4096).  A tail of <= 32 rows skips the second row tile.
+    const int nsteps = kslice / 16, ni = p.M > 32 ? 2 : 1;
+    for (int s0 = 0; s0 < nsteps; s0 += 4) {
+        bf16x8 xa[4][2], wb[4][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            xa[t] = *reinterpret_cast<const bf16x8 *>(ap[t] + 16 * s);
-            wb[t] = *reinterpret_cast<const bf16x8 *>(wp[t] + 16 * s);
+        for (int u = 0; u < 4; ++u) {
+            if (s0 + u >= nsteps) break;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (t < ni) xa[u][t] = *reinterpret_cast<const bf16x8 *>(ap[t] + 16 * (s0 + u));
+                wb[u][t] = *reinterpret_cast<const bf16x8 *>(wp[t] + 16 * (s0 + u));
+            }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int u = 0; u < 4; ++u) {
+            if (s0 + u >= nsteps) break;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) {
+                if (i >= ni) break;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[u][j], xa[u][i], acc[i][j], 0, 0, 0);
+            }
+        }
     }
     // partial tile of this wave -> LDS: acc[i][j][4g+e] = (row 32i + c32, col 32j + 8g + 4h + e)
     float *mine = part + wave * 4096;

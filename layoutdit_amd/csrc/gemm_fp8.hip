@@ -323,18 +323,32 @@ __global__ void __launch_bounds__(512, 2) gemm_fp8_skinny(const GemmArgs8 p)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-    for (int s = 0; s < kslice / 16; ++s) {
-        long xa[2], wb[2];
+    // Every wave streams its K slice straight from global memory; four steps of fragment loads are issued before the
+    // first of their MFMAs so that one memory latency covers four steps (the plain load-then-multiply loop was latency
+    // bound: 24 us for the 16-row tail of fc2 at K = 4096).  A tail of <= 32 rows skips the second row tile.
+    const int nsteps = kslice / 16, ni = p.M > 32 ? 2 : 1;
+    for (int s0 = 0; s0 < nsteps; s0 += 4) {
+        long xa[4][2], wb[4][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            xa[t] = *reinterpret_cast<const long *>(ap[t] + 16 * s);
-            wb[t] = *reinterpret_cast<const long *>(wp[t] + 16 * s);
+        for (int u = 0; u < 4; ++u) {
+            if (s0 + u >= nsteps) break;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (t < ni) xa[u][t] = *reinterpret_cast<const long *>(ap[t] + 16 * (s0 + u));
+                wb[u][t] = *reinterpret_cast<const long *>(wp[t] + 16 * (s0 + u));
+            }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int u = 0; u < 4; ++u) {
+            if (s0 + u >= nsteps) break;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(wb[j], xa[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) {
+                if (i >= ni) break;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(wb[u][j], xa[u][i], acc[i][j], 0, 0, 0);
+            }
+        }
     }
     float *mine = part + wave * 4096;
 #pragma unroll

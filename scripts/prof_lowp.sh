@@ -1,11 +1,12 @@
 #!/bin/bash
-# Kernel trace of the fp8 (or $DT) ViT-B bs=$BS forward: per-kernel durations and the gaps between them (GPU box).
+# Kernel trace of a low-precision bench line ($DT, $MODEL, $SIZE, $BS): per-kernel durations and the gaps between them
+# (GPU box).  The *_kernel_stats.csv it leaves under gpurun_out/prof_<tag>/ is what profiles/r01_cfg*_kernel_stats.csv hold.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-TAG=${1:-fp8}; DT=${DT:-fp8}; BS=${BS:-32}
+TAG=${1:-fp8}; DT=${DT:-fp8}; BS=${BS:-32}; MODEL=${MODEL:-base}; SIZE=${SIZE:-224}
 mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python3 bench.py --dtype $DT --batch $BS --steps 5 --warmup 2 --cpu-sample 0 --no-roofline-pass > gpurun_out/prof_bench_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o $TAG -- python3 bench.py --model $MODEL --size $SIZE --dtype $DT --batch $BS --steps 5 --warmup 2 --cpu-sample 0 --no-roofline-pass > gpurun_out/prof_bench_$TAG.log 2>&1
 echo "rocprofv3 rc=$?"
 python3 - <<PY
 import csv, glob, collections
