@@ -22,6 +22,16 @@
 
 #define LDIT_TRY_RC(expr) do { int rc__ = (expr); if (rc__ != LDIT_OK) return rc__; } while (0)
 
+#ifdef LDIT_GEMM_STAMPS
+// diagnostic build only (make dbg; scripts/attn_stamps.py): per-workgroup phase cycles of wave 0, written to a buffer
+// registered by ldit_dbg_set_attn_stamps - 6 x int64 per workgroup: wait+barrier, DMA issue, S = K Q^T issue,
+// softmax (incl. the wait for S), P V, kernel total
+__device__ unsigned long long *g_attn_stamps = nullptr;
+#define ATT_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define ATT_STAMP(var)
+#endif
+
 namespace ldit {
 
 namespace {
@@ -105,8 +115,13 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
     const int vlane = 64 * ((lane & 15) >> 2) + 32 * ((lane >> 4) & 1) + 8 * (lane & 3) + 512 * h;
 
     const int nchunks = (N + KC - 1) / KC;
+#ifdef LDIT_GEMM_STAMPS
+    unsigned long long tw = 0, ti = 0, ts = 0, tx = 0, tp = 0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
     issue(0, 0);
     for (int ci = 0; ci < nchunks; ++ci) {
+        ATT_STAMP(t0);
         const int c0 = ci * KC;
         const int nkeys = (N - c0) < KC ? (N - c0) : KC;
         const int ktiles = (nkeys + 31) >> 5;
@@ -136,6 +151,7 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
                     }
                 }
             }
+            ATT_STAMP(t3);
             // ---- mask padded keys (last chunk only: a real branch, not 2 VALU ops on every score), running max on the raw
             //      scores (scale > 0 commutes with max) ---------------------------------------------------------------------
             if (nkeys < KC) {
@@ -175,6 +191,7 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
             }
+            ATT_STAMP(t4);
             // ---- O^T += V^T . P^T ---------------------------------------------------------------------------------------
             // The transposing reads are inline asm: through the builtin, hipcc cannot tell that they do not alias the
             // LDS-DMA writes of the NEXT chunk and guards each group with s_waitcnt vmcnt(0), which would serialise the
@@ -212,11 +229,22 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
                         }
                 }
             }
+#ifdef LDIT_GEMM_STAMPS
+            asm volatile("s_nop 0" :: "v"(o[0][0]), "v"(o[1][0]));
+            const unsigned long long t5 = __builtin_amdgcn_s_memtime();
+            ts += t3 - t2; tx += t4 - t3; tp += t5 - t4;
+#endif
         }
         __builtin_amdgcn_s_barrier();                  // every wave is done with this stage before chunk ci+2 overwrites it
         asm volatile("" ::: "memory");
     }
 
+#ifdef LDIT_GEMM_STAMPS
+    if (g_attn_stamps && wave == 0 && lane == 0) {
+        unsigned long long *d = g_attn_stamps + (size_t)blockIdx.x * 6;
+        d[0] = tw; d[1] = ti; d[2] = ts; d[3] = tx; d[4] = tp; d[5] = __builtin_amdgcn_s_memtime() - t_begin;
+    }
+#endif
     if (!active) return;
     const float l = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = OUT_FP8 ? 1.0f / (l * qscale[0]) : 1.0f / l;
@@ -292,3 +320,11 @@ int launch_attention_bf16_fp8out(const void *Q, const void *K, const void *V, vo
 }
 
 }  // namespace ldit
+
+#ifdef LDIT_GEMM_STAMPS
+extern "C" int ldit_dbg_set_attn_stamps(void *buf)
+{
+    unsigned long long *p = static_cast<unsigned long long *>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#endif
