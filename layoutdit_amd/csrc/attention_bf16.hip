@@ -10,7 +10,7 @@
 // same key order: the transposing LDS read delivers exactly that (rows = 4 consecutive keys starting at 16s + 8u + 4h,
 // columns = the 16 d of the lane group), so V stays key-major in LDS, P never touches LDS and nothing is shuffled.
 // K and V chunks are staged by LDS-DMA (global_load_lds, no registers, no scatter writes) into a double buffer: chunk
-// c+1 flies while chunk c is multiplied.  K image: 128-B rows, 16-B chunk XOR-swizzled with (row>>1)&7 (conflict-free
+// c+1 flies while chunk c is multiplied, with a single workgroup barrier per chunk.  K image: 128-B rows, 16-B chunk XOR-swizzled with (row>>1)&7 (conflict-free
 // b128 reads); V image: 256-B blocks [4 keys][32 d] - one transposing read of a 32-lane half is exactly one block, i.e.
 // one full sweep of the 64 banks.  Rows past N are clamped duplicates of the last key and masked to -inf.
 // Softmax runs on raw scores in the exp2 domain (p = exp2(s c - m c), c = scale log2 e: one FMA + one v_exp_f32 per
@@ -125,14 +125,18 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
         const int c0 = ci * KC;
         const int nkeys = (N - c0) < KC ? (N - c0) : KC;
         const int ktiles = (nkeys + 31) >> 5;
-        if (ci + 1 < nchunks) {
-            issue((ci + 1) & 1, c0 + KC);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");   // chunk ci landed, ci+1 flies
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // ONE barrier per chunk: behind it every wave's pieces of chunk ci have landed AND every wave has finished
+        // multiplying chunk ci-1 (program order), so the other stage is free - chunk ci+1 is issued right here and has the
+        // whole of chunk ci's arithmetic to land.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        ATT_STAMP(t1);
+        if (ci + 1 < nchunks) issue((ci + 1) & 1, c0 + KC);
+        ATT_STAMP(t2);
+#ifdef LDIT_GEMM_STAMPS
+        tw += t1 - t0; ti += t2 - t1;
+#endif
         if (active) {
             const char *Ks = smem + (ci & 1) * STAGE;
             const char *Vs = Ks + HALF;
@@ -235,8 +239,6 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
             ts += t3 - t2; tx += t4 - t3; tp += t5 - t4;
 #endif
         }
-        __builtin_amdgcn_s_barrier();                  // every wave is done with this stage before chunk ci+2 overwrites it
-        asm volatile("" ::: "memory");
     }
 
 #ifdef LDIT_GEMM_STAMPS
