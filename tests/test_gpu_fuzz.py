@@ -39,6 +39,7 @@ def _cleanup():
     yield
     os.environ.pop("LDIT_GEMM_TILE", None)
     os.environ.pop("LDIT_GEMM_BF16_TILE", None)
+    os.environ.pop("LDIT_GEMM_FP8_TILE", None)
 
 
 @pytest.mark.parametrize("tile", ["auto", "0", "1", "2", "3"])
@@ -83,6 +84,31 @@ def test_fuzz_linear_bf16(tile):
         if epi == _lib.EPI_SCALE_RESID:
             ref = (r.astype(np.float64) + lam.astype(np.float64) * ref.astype(np.float64)).astype(np.float32)
         assert rel_l2(y, ref) < (1e-5 if epi == _lib.EPI_SCALE_RESID else 4e-3), (tile, M, N, K, epi)
+
+
+@pytest.mark.parametrize("tile", ["auto", "0", "1", "2"])
+def test_fuzz_linear_fp8(tile):
+    """fp8 GEMM on the same ragged shapes; reference = oracle on the dequantised codes (gates: tests/test_gpu_fp8.py)."""
+    if tile != "auto":
+        os.environ["LDIT_GEMM_FP8_TILE"] = tile
+    F8 = torch.float8_e4m3fn
+    for idx, (M, N, K) in enumerate(_cases(10, 500 + len(tile))):
+        K = 128 * ((K + 127) // 128)
+        epi = (0, 2)[idx % 2]                       # bias -> bf16, scale+residual -> fp32 (GELU -> fp8 has its own test)
+        x, w = _rand(idx, M, K), _rand(idx + 50, N, K, scale=0.1)
+        sx, sw = float(np.abs(x).max()) / 448.0, float(np.abs(w).max()) / 448.0
+        xq = (torch.from_numpy(x) * torch.tensor(np.float32(1.0 / sx))).clamp(-448.0, 448.0).to(F8)
+        wq = (torch.from_numpy(w) * torch.tensor(np.float32(1.0 / sw))).clamp(-448.0, 448.0).to(F8)
+        b, lam, r = _rand(idx + 90, N, scale=0.2), np.abs(_rand(idx + 7, N)) + 0.05, _rand(idx + 8, M, N)
+        kw = {}
+        if epi == _lib.EPI_SCALE_RESID:
+            kw = dict(lam=torch.from_numpy(lam).to(DEV), residual=torch.from_numpy(r).to(DEV))
+        y = ops.linear_fp8(xq.to(DEV), wq.to(DEV), sx * sw, torch.from_numpy(b).to(DEV), epilogue=epi, **kw).float().cpu().numpy()
+        ref = oracle.linear(xq.float().numpy(), wq.float().numpy()) * np.float32(sx * sw) + b
+        if epi == _lib.EPI_SCALE_RESID:
+            ref = (r.astype(np.float64) + lam.astype(np.float64) * ref.astype(np.float64)).astype(np.float32)
+        assert rel_l2(y, ref) < (1e-4 if epi == _lib.EPI_SCALE_RESID else 4e-3), (tile, M, N, K, epi)
+        assert np.isfinite(y).all()
 
 
 def test_fuzz_attention_lengths():
