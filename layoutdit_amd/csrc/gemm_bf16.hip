@@ -17,6 +17,13 @@
 #include "ldit_common.h"
 #include "epilogue_rows.h"
 
+#ifdef LDIT_GEMM_STAMPS
+// diagnostic build only (make dbg; scripts/gemm_bf16_stamps.py): per-workgroup cycles of wave 0 in gemm_bf16_mfma -
+// 4 x int64: k-loop total, of which waiting for its own DMA (vmcnt) at the hand-over, of which waiting at the barrier,
+// epilogue
+__device__ unsigned long long *g_gemm_bf16_stamps = nullptr;
+#endif
+
 namespace ldit {
 
 namespace {
@@ -221,6 +228,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     issue(0, 0);
     issue_range(1, (nk > 1 ? 1 : 0) * BKB, 0, D3);
     __syncthreads();
+#ifdef LDIT_GEMM_STAMPS
+    unsigned long long st_vm = 0, st_bar = 0;
+    const unsigned long long st_loop0 = __builtin_amdgcn_s_memtime();
+#endif
     load_frags(0, 0, xa0, wb0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
@@ -269,7 +280,19 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
         if (NM - NF > 0) __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF, 2);
         __builtin_amdgcn_sched_barrier(0);
         // ---- hand-over: own DMA of tile kt+1 landed (vmcnt 0), own reads of stage cur done, then all waves
+#ifdef LDIT_GEMM_STAMPS
+        {
+            const unsigned long long h0 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long h1 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const unsigned long long h2 = __builtin_amdgcn_s_memtime();
+            st_vm += h1 - h0; st_bar += h2 - h1;
+        }
+#else
         __syncthreads();
+#endif
         // ---- step 3: MFMAs of the last fragments | first fragments of tile kt+1 | first DMA pieces of tile kt+2 -> stage cur
         load_frags(cur ^ 1, 0, xa0, wb0);
         issue_range(cur, k2, 0, D3);
@@ -287,6 +310,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
         if (NM - NF - D3 > 0) __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF - D3, 3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches of the tail must not outlive the LDS allocation
+#ifdef LDIT_GEMM_STAMPS
+    asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][15]));
+    const unsigned long long st_loop1 = __builtin_amdgcn_s_memtime();
+#endif
 
     const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
@@ -297,6 +324,13 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     } else if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
     else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
     else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
+#ifdef LDIT_GEMM_STAMPS
+    if (g_gemm_bf16_stamps && wave == 0 && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long *d = g_gemm_bf16_stamps + (size_t)blockIdx.x * 4;
+        d[0] = st_loop1 - st_loop0; d[1] = st_vm; d[2] = st_bar; d[3] = __builtin_amdgcn_s_memtime() - st_loop1;
+    }
+#endif
 }
 
 template <int WM, int WN, int TM, int TN, int EPI>
@@ -809,3 +843,11 @@ int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream)
 }
 
 }  // namespace ldit
+
+#ifdef LDIT_GEMM_STAMPS
+extern "C" int ldit_dbg_set_gemm_bf16_stamps(void *buf)
+{
+    unsigned long long *p = static_cast<unsigned long long *>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_bf16_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#endif
