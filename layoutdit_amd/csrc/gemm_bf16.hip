@@ -351,279 +351,6 @@ int launch_h(const GemmArgsH &a, hipStream_t stream)
     return LDIT_OK;
 }
 
-// ---- ring kernel: 256 x 256 tile, 8 waves (2 x 4, two per SIMD), BK = 32, FOUR LDS stages, prefetch distance 3 ------
-// The simple two-stage loop above waits for vmcnt(0) at every hand-over with one tile in flight, and at bf16 MFMA rates
-// (a k-tile is ~2 k cycles per SIMD) that exposes most of the L2 latency.  Here three k-tiles are always in flight: the
-// hand-over waits with a COUNTED vmcnt (tile kt landed, tiles kt+1 and kt+2 still flying), uses a raw s_barrier (a
-// __syncthreads() would drain the DMA queue), and immediately issues tile kt+3 into the stage every wave has just left.
-// LDS rows are 64 B (32 bf16): one DMA piece = 16 rows, 16-B chunk XOR-swizzled with (row>>2)&3 on the source address
-// and on the read (16 consecutive rows x one chunk -> 16 distinct 16-B slots of the four-row bank line).
-template <int WM, int WN, int TM, int TN, int STAGES, int EPI>
-__global__ void __launch_bounds__(64 * WM * WN, 8 / (WM * WN)) gemm_bf16_ring(const GemmArgsH p)
-{
-    constexpr int NW = WM * WN, BM = 32 * TM * WM, BN = 32 * TN * WN, ROWS = BM + BN, BK = 32, RB = 64;
-    constexpr int STAGE_BYTES = ROWS * RB, NLD = ROWS / 16 / NW, DIST = STAGES - 1;
-    static_assert(ROWS % (16 * NW) == 0 && BM % 16 == 0, "DMA pieces (16 rows x 64 B) must split evenly over the waves");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int c32 = lane & 31, h = lane >> 5;
-
-    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
-    const int ntiles = nbm * nbn;
-    int tile;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = ntiles >> 3, rr = ntiles & 7;
-        tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
-    }
-    const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
-
-    unsigned src[NLD];   // bf16 element offsets
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-        const int piece = wave + NW * u, row = 16 * piece + (lane >> 2);
-        const int c = (lane & 3) ^ ((row >> 2) & 3);
-        if (16 * piece < BM) {
-            int gm = m0 + row;
-            gm = gm < p.M ? gm : p.M - 1;
-            src[u] = (unsigned)gm * (unsigned)p.lda + c * 8;
-        } else {
-            int gn = n0 + row - BM;
-            gn = gn < p.N ? gn : p.N - 1;
-            src[u] = (unsigned)gn * (unsigned)p.K + c * 8;
-        }
-    }
-    auto issue = [&](int stage, int k0) {
-        char *base = smem + stage * STAGE_BYTES;
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int piece = wave + NW * u;
-            const bf16_t *opnd = 16 * piece < BM ? p.A : p.W;
-            glds16h(opnd + (src[u] + (unsigned)k0), base + piece * 1024);
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const int nk = p.K / BK;
-    const int sw = (c32 >> 2) & 3;
-    const int a_row = (wm * TM * 32 + c32) * RB, b_row = (BM + wn * TN * 32 + c32) * RB;
-
-    // prologue: tiles 0 .. DIST-1 in flight (clamped re-fetches when K is shorter; they are harmless and counted)
-#pragma unroll
-    for (int t = 0; t < DIST; ++t) issue(t, (t < nk ? t : nk - 1) * BK);
-    int stage = 0, fill = DIST % STAGES;
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed once at most the (DIST-1)*NLD youngest DMA pieces of this wave are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * NLD) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // the stage filled now was read in the previous iteration; every wave has passed the barrier since.  Past the
-        // end the last tile is re-fetched so that the wait above keeps its meaning; drained before the epilogue.
-        issue(fill, (kt + DIST < nk ? kt + DIST : nk - 1) * BK);
-        const char *st = smem + stage * STAGE_BYTES;
-        bf16x8 xa[2][TM], wb[2][TN];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const char *base = st + (((2 * s + h) ^ sw) * 16);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) xa[s][i] = *reinterpret_cast<const bf16x8 *>(base + a_row + i * 32 * RB);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) wb[s][j] = *reinterpret_cast<const bf16x8 *>(base + b_row + j * 32 * RB);
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[s][j], xa[s][i], acc[i][j], 0, 0, 0);
-        stage = stage + 1 == STAGES ? 0 : stage + 1;
-        fill = fill + 1 == STAGES ? 0 : fill + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail re-fetches must not outlive the LDS allocation
-
-    const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
-    const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
-    if (cols_in && m0 + BM <= p.M && !p.direct_epi) {
-        __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
-        store_rows_via_lds<TM, TN, EPI, EPI == EPI_SCALE_RESID ? EPI_OUT_F32 : EPI_OUT_BF16>(
-            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, p.ldy, mw, nw, lane, 1.0f, 1.0f);
-    } else if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
-    else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
-    else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
-}
-
-template <int WM, int WN, int TM, int TN, int STAGES, int EPI>
-int launch_ring(const GemmArgsH &a, hipStream_t stream)
-{
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int lds = STAGES * (BM + BN) * 64;
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    auto kern = gemm_bf16_ring<WM, WN, TM, TN, STAGES, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), lds, stream, a);
-    LDIT_HIP_CHECK(hipGetLastError());
-    return LDIT_OK;
-}
-
-// ---- ping-pong kernel: 256 x 256 tile, 8 waves (2 x 4), BK = 32, four LDS stages, the two waves of a SIMD alternate --------
-// Free-running, the two waves that share a SIMD want the MFMA pipe at the same time and the LDS at the same time.  Here
-// they are forced out of phase: every wave's k-step is  [LOAD: 12 fragment reads of tile i] barrier [MATH: 16 MFMAs of
-// tile i] barrier,  and the wm = 1 half of the workgroup runs one barrier behind the wm = 0 half (wave w and w + 4 share
-// SIMD w % 4), so in every barrier-to-barrier slot one wave per SIMD streams MFMAs at raised priority while the other
-// refills its fragments and feeds the DMA ring.
-//   slots:    G0 tile i: LOAD 2i, MATH 2i+1        G1 tile i: LOAD 2i+1, MATH 2i+2
-//   WAR:  tile i+3 (stage of tile i-1) is issued at the head of MATH(i): G1's reads of tile i-1 (slot 2i-1) were retired by
-//         its lgkmcnt(0) in slot 2i, and every wave has passed barrier 2i+1 since.
-//   RAW:  every wave waits (counted vmcnt: only tile i+2 may still fly) for ITS pieces of tile i+1 at the end of LOAD(i),
-//         i.e. before barrier 2i+2; the first read of tile i+1 is G0's in slot 2i+2.
-template <int EPI>
-__global__ void __launch_bounds__(512, 2) gemm_bf16_pp(const GemmArgsH p)
-{
-    constexpr int WN = 4, TM = 4, TN = 2, NW = 8, BM = 256, BN = 256, ROWS = BM + BN, BK = 32, RB = 64, STAGES = 4;
-    constexpr int STAGE_BYTES = ROWS * RB, NLD = ROWS / 16 / NW;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int c32 = lane & 31, h = lane >> 5;
-
-    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
-    const int ntiles = nbm * nbn;
-    int tile;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = ntiles >> 3, rr = ntiles & 7;
-        tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
-    }
-    const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
-
-    unsigned src[NLD];   // bf16 element offsets
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-        const int piece = wave + NW * u, row = 16 * piece + (lane >> 2);
-        const int c = (lane & 3) ^ ((row >> 2) & 3);
-        if (16 * piece < BM) {
-            int gm = m0 + row;
-            gm = gm < p.M ? gm : p.M - 1;
-            src[u] = (unsigned)gm * (unsigned)p.lda + c * 8;
-        } else {
-            int gn = n0 + row - BM;
-            gn = gn < p.N ? gn : p.N - 1;
-            src[u] = (unsigned)gn * (unsigned)p.K + c * 8;
-        }
-    }
-    auto issue = [&](int stage, int k0) {
-        char *base = smem + stage * STAGE_BYTES;
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int piece = wave + NW * u;
-            const bf16_t *opnd = 16 * piece < BM ? p.A : p.W;
-            glds16h(opnd + (src[u] + (unsigned)k0), base + piece * 1024);
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const int nk = p.K / BK;
-    const int sw = (c32 >> 2) & 3;
-    const int a_row = (wm * TM * 32 + c32) * RB, b_row = (BM + wn * TN * 32 + c32) * RB;
-
-    // prologue: tiles 0, 1, 2 in flight (clamped re-fetches when K is shorter: harmless, and they keep the counts valid)
-#pragma unroll
-    for (int t = 0; t < 3; ++t) issue(t, (t < nk ? t : nk - 1) * BK);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLD) : "memory");   // tile 0
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();                       // the stagger: G1 runs one slot behind G0
-    __builtin_amdgcn_sched_barrier(0);
-
-    int stage = 0, fill = 3;
-    for (int kt = 0; kt < nk; ++kt) {
-        // ---- LOAD slot -----------------------------------------------------------------------------------------------
-        const char *st = smem + stage * STAGE_BYTES;
-        bf16x8 xa[2][TM], wb[2][TN];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const char *base = st + (((2 * s + h) ^ sw) * 16);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) wb[s][j] = *reinterpret_cast<const bf16x8 *>(base + b_row + j * 32 * RB);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) xa[s][i] = *reinterpret_cast<const bf16x8 *>(base + a_row + i * 32 * RB);
-        }
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");    // this wave's pieces of tile kt+1 have landed
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- MATH slot -----------------------------------------------------------------------------------------------
-        issue(fill, (kt + 3 < nk ? kt + 3 : nk - 1) * BK);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[s][j], xa[s][i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        stage = (stage + 1) & (STAGES - 1);
-        fill = (fill + 1) & (STAGES - 1);
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();                       // pairs with G1's extra barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail re-fetches must not outlive the LDS allocation
-
-    const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
-    const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
-    if (cols_in && m0 + BM <= p.M && !p.direct_epi) {
-        __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
-        store_rows_via_lds<TM, TN, EPI, EPI == EPI_SCALE_RESID ? EPI_OUT_F32 : EPI_OUT_BF16>(
-            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, p.ldy, mw, nw, lane, 1.0f, 1.0f);
-    } else if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
-    else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
-    else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
-}
-
-template <int EPI>
-int launch_pp(const GemmArgsH &a, hipStream_t stream)
-{
-    constexpr int lds = 4 * 512 * 64;
-    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-    auto kern = gemm_bf16_pp<EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, stream, a);
-    LDIT_HIP_CHECK(hipGetLastError());
-    return LDIT_OK;
-}
-
 // ---- skinny kernel: up to 64 rows (the ragged tail peeled off by launch_gemm_bf16) -----------------------------------
 // A 16-row remainder on a 128 x 128 tile is a serial K loop of ~0.4 us per k-tile (24 us at K = 4096) with 8 workgroups
 // on the machine.  Here a workgroup owns 64 rows x 64 columns and its EIGHT waves split K: every wave multiplies the
@@ -747,11 +474,9 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
     //   256 x 256, 8 waves (one workgroup per CU):  strict rounds of 256 tiles, each  a[epi] + 19.5e-3 K
     //   128 x 128 (two per CU, they overlap each other's prologue / epilogue):  rounds of 256 tiles, each  r[epi] + 7.6e-3 K,
     //   but never less than one tile's own latency  5 + 11.4e-3 K.
-    // (256 x 128 and the ring / ping-pong variants never won a shape by more than a few percent: kept for experiments only;
-    //  a v_mfma_f32_16x16x32_bf16 build of this kernel - same LDS image, conflict-free for that lane map too - measured
-    //  equal to the 32x32x16 one on every shape, 432.6 vs 432.2 us per ViT-L layer, and was dropped.
-    //  A 288 x 256 four-wave "panel" instantiation <1,4,9,2> fixes the tile quantisation at M = 16 x 1025 but needs the
-    //  pinned DMA/read schedule of gemm_panel_f32.hip to pay off: naive it spills and ran 439 vs 599 TFLOP/s)
+    // Measured and dropped (profiles/README.md): a four-stage and a five-stage counted-vmcnt ring, a 256 x 128 ring at two
+    // workgroups per CU, a barrier-phased ping-pong of the two waves per SIMD, a v_mfma_f32_16x16x32_bf16 build and a
+    // four-wave 256 x 256 tile - none beat this kernel on any shape; the 256 x 128 tile stays selectable for experiments.
     const double a256[3] = {19.0, 18.5, 25.0}, r128[3] = {5.2, 5.0, 7.7};
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const double c256 = (double)((t256 + 255) / 256) * (a256[EPI] + 19.5e-3 * a.K);
@@ -759,14 +484,10 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
     if (c128 < 5.0 + 11.4e-3 * a.K) c128 = 5.0 + 11.4e-3 * a.K;
     int pick = c256 <= c128 ? 3 : 2;
     if (const char *force = getenv("LDIT_GEMM_BF16_TILE")) {
-        if (force[0] >= '0' && force[0] <= '6' && force[1] == 0) pick = force[0] - '0';
+        if (force[0] >= '1' && force[0] <= '3' && force[1] == 0) pick = force[0] - '0';
     }
-    if (pick == 6) return launch_pp<EPI>(a, stream);                      // 256 x 256 ping-pong
-    if (pick == 4) return launch_ring<2, 4, 4, 2, 4, EPI>(a, stream);    // 256 x 256, 8 waves, 4 stages (1 workgroup per CU)
-    if (pick == 5) return launch_ring<2, 2, 4, 2, 3, EPI>(a, stream);    // 256 x 128, 4 waves, 3 stages: 72 KB -> 2 workgroups per CU
     switch (pick) {
         case 3: return launch_h<2, 4, 4, 2, EPI>(a, stream);     // 256 x 256, 8 waves (2 per SIMD)
-        case 0: return launch_h<2, 2, 4, 4, EPI>(a, stream);     // 256 x 256, 4 waves
         case 1: return launch_h<2, 2, 4, 2, EPI>(a, stream);     // 256 x 128, 4 waves
         default: return launch_h<2, 2, 2, 2, EPI>(a, stream);    // 128 x 128, 4 waves
     }
