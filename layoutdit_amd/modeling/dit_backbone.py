@@ -24,12 +24,13 @@ from .dit_encoder import DiTEncoder
 
 class DiTBackbone(nn.Module):
     def __init__(self, pretrained: bool = False, config: Optional[DiTConfig] = None,
-                 checkpoint: Optional[str] = None):
+                 checkpoint: Optional[str] = None, compute_dtype: str = "f32"):
         """``pretrained=True`` in the reference means a hub download; offline it must come with a local
         ``checkpoint`` path (a ``state_dict`` in any of the accepted BEiT key layouts, loaded with
-        ``weights_only=True``)."""
+        ``weights_only=True``).  ``compute_dtype`` selects the encoder build (``"f32"``, ``"bf16"``, ``"fp8"`` - the
+        last needs ``self.dit.calibrate_fp8(sample)`` once); the returned maps are fp32 in every build."""
         super().__init__()
-        self.dit = DiTEncoder(config)
+        self.dit = DiTEncoder(config, compute_dtype=compute_dtype)
         if pretrained and checkpoint is None:
             raise ValueError("pretrained=True needs checkpoint=<local state_dict path>: there is no hub access "
                              "(the reference fetches microsoft/dit-base, ref dit_backbone.py:25-31)")
