@@ -42,7 +42,8 @@ enum ldit_dtype {
     LDIT_BF16 = 1, /* GEMM / attention operands bf16, fp32 accumulation, residual stream / LayerNorm / softmax fp32; taps fp32 */
     LDIT_FP8 = 3   /* BASELINE.json configs[4]: the four GEMMs of a layer on fp8 e4m3 (OCP) operands with per-tensor scales,
                       fp32 accumulation; attention on bf16 q|k|v; residual stream / LayerNorm / softmax fp32; taps fp32.
-                      Weight scales are measured by ldit_pack_weights; the four activation scales per layer come from
+                      Weight scales (one per output channel) are measured by ldit_pack_weights; the four per-tensor
+                      activation scales per layer come from
                       ldit_set_fp8_act_scales (calibration is the caller's job) */
 };
 
@@ -191,17 +192,22 @@ int ldit_attention_bf16(const void *Q, const void *K, const void *V, void *O, in
 /* dst[i] = bf16(src[i]) (round to nearest even), n elements. */
 int ldit_cast_f32_bf16(const void *src, void *dst, int64_t n, ldit_stream stream);
 
-/* ---- fp8 (OCP e4m3) building blocks: groundwork for BASELINE.json configs[4] (fp8 forward) ---------------------------
- * Per-tensor symmetric scaling: a tensor T is held as fp8 codes q with T ~= scale_T * q, scale_T = amax(T) / 448.
+/* ---- fp8 (OCP e4m3) building blocks of the fp8 build (BASELINE.json configs[4]) -----------------------------------------
+ * Symmetric scaling: activations per tensor (T ~= scale_T * q, scale_T = amax(T) / 448), weights per output channel
+ * (W[n,:] ~= w_scales[n] * q[n,:]).
  *
- * ldit_linear_fp8:  Y = epilogue(ab_scale * (X8 . W8^T) + bias)  with X8 [M,K] (row stride lda BYTES = elements) and
- * W8 [N,K] fp8 e4m3, fp32 accumulation (v_mfma_f32_32x32x16_fp8_fp8), ab_scale = scale_X * scale_W.  K % 128 == 0,
- * lda % 16 == 0.  bias / lam fp32.  LDIT_EPI_BIAS writes bf16 Y; LDIT_EPI_BIAS_GELU writes fp8 Y =
+ * ldit_linear_fp8:  Y = epilogue(ab_scale * w_scales[n] * (X8 . W8^T) + bias)  with X8 [M,K] (row stride lda BYTES =
+ * elements) and W8 [N,K] fp8 e4m3, fp32 accumulation (v_mfma_f32_32x32x64_f8f6f4).  w_scales: device fp32 [N] or NULL
+ * (then ab_scale = scale_X * scale_W, per tensor).  K % 128 == 0, lda % 16 == 0.  bias / lam fp32.  LDIT_EPI_BIAS writes bf16 Y; LDIT_EPI_BIAS_GELU writes fp8 Y =
  * sat(gelu(.) * out_inv_scale) (ldy in elements); LDIT_EPI_SCALE_RESID reads the fp32 residual R (may alias Y),
  * writes fp32 Y and the optional fp32 copy Y2. */
 int ldit_linear_fp8(const void *X, int64_t lda, const void *W, const void *bias, void *Y, int64_t ldy, int64_t M, int64_t N,
                     int64_t K, int32_t epilogue, const void *lam, const void *R, void *Y2, float ab_scale,
-                    float out_inv_scale, ldit_stream stream);
+                    float out_inv_scale, const void *w_scales, ldit_stream stream);
+
+/* Per-output-channel weight quantisation: scales[n] = max|W[n,:]| / 448 (never 0), codes[n,:] = fp8(W[n,:] / scales[n]).
+ * W fp32 [N,K] row-major, K % 4 == 0. */
+int ldit_quant_rows_f32_fp8(const void *W, void *codes, void *scales, int64_t N, int64_t K, ldit_stream stream);
 
 /* dst[i] = fp8_e4m3(src[i] * inv_scale), round to nearest even, SATURATING at +-448 (torch's cast yields NaN above
  * 464 instead); n elements, src 16-byte aligned, dst 4-byte aligned. */

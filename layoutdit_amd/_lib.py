@@ -60,7 +60,8 @@ SIGNATURES = {
     "ldit_linear_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "ldit_attention_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ldit_cast_f32_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
-    "ldit_linear_fp8": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _f32, _f32, _vp]),
+    "ldit_linear_fp8": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
+    "ldit_quant_rows_f32_fp8": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "ldit_set_fp8_act_scales": (C.c_int, [C.POINTER(LditCfg), _vp, C.c_size_t, C.POINTER(C.c_float), _vp]),
     "ldit_quant_f32_fp8": (C.c_int, [_vp, _vp, _i64, _f32, _vp]),
     "ldit_amax_f32": (C.c_int, [_vp, _i64, _vp, _vp]),

@@ -2,8 +2,6 @@
 // arithmetic happens in the HIP kernels of this directory; there is no CPU fallback.
 #include <cmath>
 #include <cstring>
-#include <initializer_list>
-#include <utility>
 #include <vector>
 
 #include "ldit_common.h"
@@ -59,9 +57,10 @@ int geometry(const ldit_cfg *cfg, Geo &g)
 
 // Byte offsets into the packed parameter block; every offset is a multiple of 16 bytes.  In the bf16 build the four
 // big matrices of a layer (fused q|k|v, o_proj, fc1, fc2) are stored as bf16, in the fp8 build as e4m3 codes; everything
-// else stays fp32.  fp8 adds 8 floats of scales per layer, ordered so that each GEMM finds {activation scale, weight
-// scale} adjacent: [a_ln1, w_qkv, a_attn, w_o, a_ln2, w_fc1, a_gelu, w_fc2].
-struct PackedLayer { size_t ln1_w, ln1_b, wqkv, bqkv, wo, bo, lam1, ln2_w, ln2_b, w1, b1, w2, b2, lam2, scales; };
+// else stays fp32.  fp8 adds, per layer, one fp32 scale per output channel of each matrix (sw_*: measured and applied by
+// ldit_pack_weights) and a block of 8 floats whose slots 0, 2, 4, 6 hold the activation scales a_ln1, a_attn, a_ln2,
+// a_gelu (ldit_set_fp8_act_scales; the odd slots are spare).
+struct PackedLayer { size_t ln1_w, ln1_b, wqkv, bqkv, wo, bo, lam1, ln2_w, ln2_b, w1, b1, w2, b2, lam2, scales, sw_qkv, sw_o, sw_1, sw_2; };
 struct PackedMap {
     size_t patch_w, patch_b, cls, pos, total;
     std::vector<PackedLayer> layer;
@@ -87,6 +86,10 @@ PackedMap packed_map(const Geo &g, int dtype)
         pl.w1 = take((size_t)g.F * g.C, mat); pl.b1 = take(g.F, 4);
         pl.w2 = take((size_t)g.C * g.F, mat); pl.b2 = take(g.C, 4); pl.lam2 = take(g.C, 4);
         pl.scales = dtype == LDIT_FP8 ? take(8, 4) : 0;
+        pl.sw_qkv = dtype == LDIT_FP8 ? take((size_t)3 * g.C, 4) : 0;
+        pl.sw_o = dtype == LDIT_FP8 ? take(g.C, 4) : 0;
+        pl.sw_1 = dtype == LDIT_FP8 ? take(g.F, 4) : 0;
+        pl.sw_2 = dtype == LDIT_FP8 ? take(g.C, 4) : 0;
     }
     m.total = o;
     return m;
@@ -242,17 +245,17 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
             const float *sc = F32(pl.scales);
             LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_fp8out(h, F32(pl.ln1_w), F32(pl.ln1_b), y8, M, C, cfg->ln_eps, sc + 0, stream));
             LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_fp8(y8, C, P + pl.wqkv, F32(pl.bqkv), bb, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr,
-                                                        nullptr, nullptr, 0.f, 0.f, sc + 0, nullptr, stream));
+                                                        nullptr, nullptr, 0.f, 0.f, sc + 0, F32(pl.sw_qkv), nullptr, stream));
             LDIT_RUN(probe, LDIT_K_ATTENTION,
                      launch_attention_bf16_fp8out(bb, bb + 2 * (size_t)C, bb + 4 * (size_t)C, y8, batch, g.T, g.H, g.D, 3 * C, 3 * C,
                                                   3 * C, C, scale, sc + 2, stream));
             LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_fp8(y8, C, P + pl.wo, F32(pl.bo), h, C, M, C, C, EPI_SCALE_RESID, F32(pl.lam1), h,
-                                                        nullptr, 0.f, 0.f, sc + 2, nullptr, stream));
+                                                        nullptr, 0.f, 0.f, sc + 2, F32(pl.sw_o), nullptr, stream));
             LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_fp8out(h, F32(pl.ln2_w), F32(pl.ln2_b), y8, M, C, cfg->ln_eps, sc + 4, stream));
             LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_fp8(y8, C, P + pl.w1, F32(pl.b1), bb, F, M, F, C, EPI_BIAS_GELU, nullptr, nullptr,
-                                                        nullptr, 0.f, 0.f, sc + 4, sc + 6, stream));
+                                                        nullptr, 0.f, 0.f, sc + 4, F32(pl.sw_1), sc + 6, stream));
             LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_fp8(bb, F, P + pl.w2, F32(pl.b2), h, C, M, C, F, EPI_SCALE_RESID, F32(pl.lam2), h,
-                                                        tap, 0.f, 0.f, sc + 6, nullptr, stream));
+                                                        tap, 0.f, 0.f, sc + 6, F32(pl.sw_2), nullptr, stream));
         } else if (!bf16) {
             // y = LN1(h)                                                               TF:426
             LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm(h, F32(pl.ln1_w), F32(pl.ln1_b), y, M, C, cfg->ln_eps, stream));
@@ -322,30 +325,22 @@ int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     char *P = static_cast<char *>(packed);
     const bool bf16 = cfg->dtype == LDIT_BF16, fp8 = cfg->dtype == LDIT_FP8;
-    float *cur_scale = nullptr;
     auto put = [&](size_t off, const void *src, size_t n, const char *what) -> int {      // fp32 copy
         if (!src) return fail(LDIT_EINVAL, "weights: %s is null", what);
         LDIT_HIP_CHECK(hipMemcpyAsync(P + off, src, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
         return LDIT_OK;
     };
-    auto put_mat = [&](size_t off, size_t elt_off, const void *src, size_t n, const char *what) -> int {   // matrix: fp32 or -> bf16
+    // matrix [rows, cols] at element offset elt_off of the block at `off`: fp32 copy, -> bf16, or -> fp8 codes with one
+    // scale per row written to the fp32 vector at sw_off (+ row0)
+    auto put_mat = [&](size_t off, size_t elt_off, const void *src, size_t rows, size_t cols, size_t sw_off, size_t row0,
+                       const char *what) -> int {
         if (!src) return fail(LDIT_EINVAL, "weights: %s is null", what);
-        if (!bf16 && !fp8) return put(off + elt_off * 4, src, n, what);
+        if (!bf16 && !fp8) return put(off + elt_off * 4, src, rows * cols, what);
         if (!aligned16(src)) return fail(LDIT_EINVAL, "weights: %s must be 16-byte aligned", what);
-        if (fp8) return launch_quant_fp8(static_cast<const float *>(src), P + off + elt_off, n, 0.f, cur_scale, stream);
-        return launch_cvt_bf16(static_cast<const float *>(src), P + off + elt_off * 2, n, stream);
-    };
-    // fp8: measure the per-tensor weight scale (amax / 448) of up to three source tensors into the layer's scale slot
-    auto measure = [&](size_t scales_off, int slot, std::initializer_list<std::pair<const void *, size_t>> parts) -> int {
-        if (!fp8) return LDIT_OK;
-        cur_scale = reinterpret_cast<float *>(P + scales_off) + slot;
-        bool first = true;
-        for (const auto &pr : parts) {
-            if (!pr.first) return fail(LDIT_EINVAL, "weights: null matrix");
-            LDIT_TRY(launch_amax_f32(static_cast<const float *>(pr.first), pr.second, cur_scale, !first, stream));
-            first = false;
-        }
-        return launch_amax_to_scale(cur_scale, 1, stream);
+        if (fp8)
+            return launch_quant_rows_fp8(static_cast<const float *>(src), P + off + elt_off,
+                                         reinterpret_cast<float *>(P + sw_off) + row0, (int)rows, (int)cols, stream);
+        return launch_cvt_bf16(static_cast<const float *>(src), P + off + elt_off * 2, rows * cols, stream);
     };
     const size_t C = g.C, F = g.F;
     LDIT_TRY(put(pm.patch_w, w->patch_w, C * g.Kp, "patch_w"));
@@ -358,24 +353,20 @@ int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, 
         LDIT_TRY(put(pl.ln1_w, s.ln1_w, C, "ln1_w"));
         LDIT_TRY(put(pl.ln1_b, s.ln1_b, C, "ln1_b"));
         if (fp8) LDIT_HIP_CHECK(hipMemsetAsync(P + pl.scales, 0, 8 * sizeof(float), stream));
-        LDIT_TRY(measure(pl.scales, 1, {{s.wq, C * C}, {s.wk, C * C}, {s.wv, C * C}}));
-        LDIT_TRY(put_mat(pl.wqkv, 0, s.wq, C * C, "wq"));
-        LDIT_TRY(put_mat(pl.wqkv, C * C, s.wk, C * C, "wk"));
-        LDIT_TRY(put_mat(pl.wqkv, 2 * C * C, s.wv, C * C, "wv"));
+        LDIT_TRY(put_mat(pl.wqkv, 0, s.wq, C, C, pl.sw_qkv, 0, "wq"));
+        LDIT_TRY(put_mat(pl.wqkv, C * C, s.wk, C, C, pl.sw_qkv, C, "wk"));
+        LDIT_TRY(put_mat(pl.wqkv, 2 * C * C, s.wv, C, C, pl.sw_qkv, 2 * C, "wv"));
         if (!s.bq || !s.bv) return fail(LDIT_EINVAL, "weights: bq / bv is null");
         LDIT_TRY(launch_pack_qkv_bias(static_cast<const float *>(s.bq), static_cast<const float *>(s.bv),
                                       reinterpret_cast<float *>(P + pl.bqkv), g.C, stream));
-        LDIT_TRY(measure(pl.scales, 3, {{s.wo, C * C}}));
-        LDIT_TRY(put_mat(pl.wo, 0, s.wo, C * C, "wo"));
+        LDIT_TRY(put_mat(pl.wo, 0, s.wo, C, C, pl.sw_o, 0, "wo"));
         LDIT_TRY(put(pl.bo, s.bo, C, "bo"));
         LDIT_TRY(put(pl.lam1, s.lam1, C, "lam1"));
         LDIT_TRY(put(pl.ln2_w, s.ln2_w, C, "ln2_w"));
         LDIT_TRY(put(pl.ln2_b, s.ln2_b, C, "ln2_b"));
-        LDIT_TRY(measure(pl.scales, 5, {{s.w1, F * C}}));
-        LDIT_TRY(put_mat(pl.w1, 0, s.w1, F * C, "w1"));
+        LDIT_TRY(put_mat(pl.w1, 0, s.w1, F, C, pl.sw_1, 0, "w1"));
         LDIT_TRY(put(pl.b1, s.b1, F, "b1"));
-        LDIT_TRY(measure(pl.scales, 7, {{s.w2, C * F}}));
-        LDIT_TRY(put_mat(pl.w2, 0, s.w2, C * F, "w2"));
+        LDIT_TRY(put_mat(pl.w2, 0, s.w2, C, F, pl.sw_2, 0, "w2"));
         LDIT_TRY(put(pl.b2, s.b2, C, "b2"));
         LDIT_TRY(put(pl.lam2, s.lam2, C, "lam2"));
     }
@@ -524,9 +515,10 @@ int ldit_cast_f32_bf16(const void *src, void *dst, int64_t n, ldit_stream stream
 
 int ldit_linear_fp8(const void *X, int64_t lda, const void *W, const void *bias, void *Y, int64_t ldy, int64_t M, int64_t N,
                     int64_t K, int32_t epilogue, const void *lam, const void *R, void *Y2, float ab_scale, float out_inv_scale,
-                    ldit_stream stream)
+                    const void *w_scales, ldit_stream stream)
 {
     if (M <= 0 || N <= 0 || K <= 0) return fail(LDIT_EINVAL, "linear_fp8: empty problem");
+    if (w_scales && !aligned16(w_scales)) return fail(LDIT_EINVAL, "linear_fp8: w_scales must be 16-byte aligned");
     if (M * (ldy > lda ? ldy : lda) >= (1ll << 31) || N * K >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "linear_fp8: operand exceeds 2^31 elements");
     if (ldy < N || lda < K) return fail(LDIT_EINVAL, "linear_fp8: bad leading dimension");
     if (!Y || (reinterpret_cast<uintptr_t>(Y) & 15u) || (Y2 && !aligned16(Y2))) return fail(LDIT_EINVAL, "linear_fp8: output null or misaligned");
@@ -534,7 +526,15 @@ int ldit_linear_fp8(const void *X, int64_t lda, const void *W, const void *bias,
     if (!(ab_scale > 0.0f) || (epilogue == LDIT_EPI_BIAS_GELU && !(out_inv_scale > 0.0f))) return fail(LDIT_EINVAL, "linear_fp8: scales must be positive");
     return launch_gemm_fp8(X, (int)lda, W, static_cast<const float *>(bias), Y, (int)ldy, (int)M, (int)N, (int)K, epilogue,
                            static_cast<const float *>(lam), static_cast<const float *>(R), static_cast<float *>(Y2), ab_scale,
-                           out_inv_scale, nullptr, nullptr, static_cast<hipStream_t>(stream));
+                           out_inv_scale, nullptr, static_cast<const float *>(w_scales), nullptr, static_cast<hipStream_t>(stream));
+}
+
+int ldit_quant_rows_f32_fp8(const void *W, void *codes, void *scales, int64_t N, int64_t K, ldit_stream stream)
+{
+    if (N <= 0 || K <= 0 || N >= (1ll << 31) || K >= (1ll << 31)) return fail(LDIT_EINVAL, "quant_rows_fp8: bad shape");
+    if (!codes || (reinterpret_cast<uintptr_t>(codes) & 3u)) return fail(LDIT_EINVAL, "quant_rows_fp8: codes null or misaligned");
+    return launch_quant_rows_fp8(static_cast<const float *>(W), codes, static_cast<float *>(scales), (int)N, (int)K,
+                                 static_cast<hipStream_t>(stream));
 }
 
 int ldit_quant_f32_fp8(const void *src, void *dst, int64_t n, float inv_scale, ldit_stream stream)

@@ -20,50 +20,54 @@ constexpr int EPI_WAVE_BYTES = 32 * EPI_ROW_BYTES;    // one 32 x 64 slab per wa
 enum { EPI_OUT_BF16 = 0, EPI_OUT_FP8 = 1, EPI_OUT_F32 = 2 };
 
 // acc: the wave's TM x TN tiles; (mw, nw): its first row / column; buf: EPI_WAVE_BYTES of LDS private to this wave.
-// t = fma(acc, ab, bias) ; GELU ; (resid: fma(lam, t, R)) ; bf16 / fp8 (times oinv, saturating) / fp32 (+ copy to Y2).
-// The arithmetic is spelled with explicit fmas, identically to the direct stores of the ragged tiles, so that a row gets
-// the same bits whichever path its tile takes (batch invariance of the bf16 / fp8 builds).
+// The RAW accumulators travel through LDS; all arithmetic happens on the read-back side, where a lane owns four fixed
+// columns (one bias / scale / lambda quad per 64-column slab instead of eight):
+//   t = fma(acc, ab * wscale[n], bias[n]) ; GELU ; (resid: fma(lam[n], t, R)) ; bf16 / fp8 (times oinv, saturating) / fp32.
+// `wscale` (optional, fp8 build) = per-output-channel weight scales; `ab` = the per-tensor part (activation scale, or
+// activation x weight scale when wscale is null; 1 for bf16).  The arithmetic is spelled with explicit fmas, identically
+// to the direct stores of the ragged tiles, so that a row gets the same bits whichever path its tile takes (batch
+// invariance of the bf16 / fp8 builds).
 template <int TM, int TN, int EPI, int OUT>
 __device__ __forceinline__ void store_rows_via_lds(const f32x16 (&acc)[TM][TN], char *buf, void *Yv, float *Y2, const float *R,
-                                                   const float *bias, const float *lam, int ldy, int mw, int nw, int lane,
-                                                   float ab, float oinv)
+                                                   const float *bias, const float *lam, const float *wscale, int ldy, int mw,
+                                                   int nw, int lane, float ab, float oinv)
 {
     static_assert(TN % 2 == 0, "slabs are 64 columns wide");
     const int c32 = lane & 31, h = lane >> 5;
     const int rrow = lane >> 4, rq = lane & 15;       // read-back: 4 rows per pass, 16 lanes x 4 columns per row
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int jp = 0; jp < TN / 2; ++jp) {
-        f32x4 bq[2][4];
+        const unsigned n = (unsigned)(nw + 64 * jp + 4 * rq);
+        const f32x4 biasq = bias ? *reinterpret_cast<const f32x4 *>(bias + n) : zero4;
+        const f32x4 lamq = EPI == EPI_SCALE_RESID ? *reinterpret_cast<const f32x4 *>(lam + n) : zero4;
+        f32x4 abq = {ab, ab, ab, ab};
+        if (wscale) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(wscale + n);
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nw + 64 * jp + 32 * jj + 8 * g + 4 * h;
-                bq[jj][g] = bias ? *reinterpret_cast<const f32x4 *>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        const f32x4 lamq = EPI == EPI_SCALE_RESID ? *reinterpret_cast<const f32x4 *>(lam + nw + 64 * jp + 4 * rq)
-                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int e = 0; e < 4; ++e) abq[e] = ab * w[e];
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float t = __builtin_fmaf(acc[i][2 * jp + jj][4 * g + e], ab, bq[jj][g][e]);
-                        if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
-                        v[e] = t;
-                    }
+                    const f32x4 v = {acc[i][2 * jp + jj][4 * g + 0], acc[i][2 * jp + jj][4 * g + 1], acc[i][2 * jp + jj][4 * g + 2],
+                                     acc[i][2 * jp + jj][4 * g + 3]};
                     *reinterpret_cast<f32x4 *>(buf + c32 * EPI_ROW_BYTES + (32 * jj + 8 * g + 4 * h) * 4) = v;
                 }
-            const unsigned n = (unsigned)(nw + 64 * jp + 4 * rq);
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int row = 4 * r + rrow;
                 f32x4 v = *reinterpret_cast<const f32x4 *>(buf + row * EPI_ROW_BYTES + rq * 16);
                 const unsigned o = (unsigned)(mw + 32 * i + row) * (unsigned)ldy + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = __builtin_fmaf(v[e], abq[e], biasq[e]);
+                    if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
+                    v[e] = t;
+                }
                 if (OUT == EPI_OUT_F32) {
                     if (EPI == EPI_SCALE_RESID) {
                         const f32x4 res = *reinterpret_cast<const f32x4 *>(R + o);

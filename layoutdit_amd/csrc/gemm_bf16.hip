@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     if (cols_in && m0 + BM <= p.M && !p.direct_epi) {
         __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
         store_rows_via_lds<TM, TN, EPI, EPI == EPI_SCALE_RESID ? EPI_OUT_F32 : EPI_OUT_BF16>(
-            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, p.ldy, mw, nw, lane, 1.0f, 1.0f);
+            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, nullptr, p.ldy, mw, nw, lane, 1.0f, 1.0f);
     } else if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
     else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
     else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);

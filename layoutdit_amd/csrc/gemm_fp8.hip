@@ -34,9 +34,10 @@ struct GemmArgs8 {
     float *Y2;                    // optional fp32 tap copy (SCALE_RESID)
     const float *bias, *lam, *R;
     int M, N, K, lda, ldy;
-    float ab_scale;               // sa * sw: dequantisation of the accumulator
+    float ab_scale;               // per-tensor dequantisation of the accumulator: sa * sw, or sa alone when d_wrow is given
     float out_inv_scale;          // 1 / scale of the fp8 output (BIAS_GELU)
-    const float *d_ab, *d_out;    // device-resident {sa, sw} / {so}: override the two host values when non-null
+    const float *d_act, *d_out;   // device-resident sa / so: override the two host values when non-null
+    const float *d_wrow;          // optional per-output-channel weight scales [N] (multiplied onto the per-tensor part)
     int direct_epi;               // LDIT_GEMM_DIRECT_EPILOGUE=1: interior tiles stored straight from the accumulators
 };
 
@@ -48,11 +49,11 @@ __device__ __forceinline__ void store_q(const GemmArgs8 &p, const f32x16 (&acc)[
 {
     const int c32 = lane & 31, h = lane >> 5;
     const bool dual = p.Y2 != nullptr;
-    const float ab = p.d_ab ? p.d_ab[0] * p.d_ab[1] : p.ab_scale;
+    const float ab = p.d_act ? p.d_act[0] : p.ab_scale;
     const float oinv = (EPI == EPI_BIAS_GELU && p.d_out) ? 1.0f / p.d_out[0] : p.out_inv_scale;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        f32x4 bias[4], lam[4];
+        f32x4 bias[4], lam[4], abq[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -61,6 +62,7 @@ __device__ __forceinline__ void store_q(const GemmArgs8 &p, const f32x16 (&acc)[
                 const bool ok = MODE != 2 || n < p.N;
                 bias[g][e] = (ok && p.bias) ? p.bias[n] : 0.0f;
                 lam[g][e] = (EPI == EPI_SCALE_RESID && ok) ? p.lam[n] : 0.0f;
+                abq[g][e] = (ok && p.d_wrow) ? ab * p.d_wrow[n] : ab;
             }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -86,7 +88,7 @@ __device__ __forceinline__ void store_q(const GemmArgs8 &p, const f32x16 (&acc)[
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = __builtin_fmaf(acc[i][j][4 * g + e], ab, bias[g][e]);
+                    float t = __builtin_fmaf(acc[i][j][4 * g + e], abq[g][e], bias[g][e]);
                     if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
                     if (EPI == EPI_SCALE_RESID) t = __builtin_fmaf(lam[g][e], t, res[g][e]);
                     v[e] = t;
@@ -267,10 +269,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_fp8_mfma(con
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
     if (cols_in && m0 + BM <= p.M && !p.direct_epi) {
         __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
-        const float ab = p.d_ab ? p.d_ab[0] * p.d_ab[1] : p.ab_scale;
+        const float ab = p.d_act ? p.d_act[0] : p.ab_scale;
         const float oinv = (EPI == EPI_BIAS_GELU && p.d_out) ? 1.0f / p.d_out[0] : p.out_inv_scale;
         store_rows_via_lds<TM, TN, EPI, EPI == EPI_SCALE_RESID ? EPI_OUT_F32 : EPI == EPI_BIAS_GELU ? EPI_OUT_FP8 : EPI_OUT_BF16>(
-            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, p.ldy, mw, nw, lane, ab, oinv);
+            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, p.d_wrow, p.ldy, mw, nw, lane, ab, oinv);
     } else if (cols_in && m0 + BM <= p.M) store_q<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
     else if (cols_in) store_q<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
     else store_q<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
@@ -371,13 +373,13 @@ __global__ void __launch_bounds__(512, 2) gemm_fp8_skinny(const GemmArgs8 p)
         for (int e = 0; e < 4; ++e) { s0[e] += a0[e]; s1[e] += a1[e]; }
     }
     if (row >= p.M) return;
-    const float ab = p.d_ab ? p.d_ab[0] * p.d_ab[1] : p.ab_scale;
+    const float ab = p.d_act ? p.d_act[0] : p.ab_scale;
     const float oinv = (EPI == EPI_BIAS_GELU && p.d_out) ? 1.0f / p.d_out[0] : p.out_inv_scale;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int n = n0 + col + e;
         if (n >= p.N) break;
-        float t = __builtin_fmaf(e < 4 ? s0[e] : s1[e - 4], ab, p.bias ? p.bias[n] : 0.0f);
+        float t = __builtin_fmaf(e < 4 ? s0[e] : s1[e - 4], p.d_wrow ? ab * p.d_wrow[n] : ab, p.bias ? p.bias[n] : 0.0f);
         const size_t o = (size_t)row * p.ldy + n;
         if (EPI == EPI_BIAS_GELU) {
             static_cast<unsigned char *>(p.Y)[o] = (unsigned char)pack_fp8x4(gelu_erf_lp(t) * oinv, 0.f, 0.f, 0.f);
@@ -467,6 +469,31 @@ __global__ void __launch_bounds__(256) amax_f32(const float *__restrict__ src, s
 }
 
 
+// One wave per weight row: scale[n] = max(|W[n, :]|) / 448 (never 0), codes[n, :] = fp8(W[n, :] / scale[n]).
+// Per-output-channel scales cost nothing in the GEMM (one more factor on the accumulator in the epilogue) and keep
+// a few large rows from flattening all the others.
+__global__ void __launch_bounds__(256) quant_rows_fp8(const float *__restrict__ W, unsigned char *__restrict__ dst,
+                                                      float *__restrict__ scales, int N, int K)
+{
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const f32x4 *w4 = reinterpret_cast<const f32x4 *>(W + (size_t)row * K);
+    float m = 0.0f;
+    for (int i = lane; i < K / 4; i += 64) {
+        const f32x4 v = w4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float sc = fmaxf(m, 1e-30f) * (1.0f / 448.0f), inv = 1.0f / sc;
+    if (lane == 0) scales[row] = sc;
+    unsigned *d4 = reinterpret_cast<unsigned *>(dst + (size_t)row * K);
+    for (int i = lane; i < K / 4; i += 64) {
+        const f32x4 v = w4[i];
+        d4[i] = pack_fp8x4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+    }
+}
+
 __global__ void amax_to_scale(float *p, int n)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
@@ -477,32 +504,32 @@ __global__ void amax_to_scale(float *p, int n)
 
 static int launch_gemm_fp8_one(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K,
                                int epi, const float *lam, const float *R, float *Y2, float ab_scale, float out_inv_scale,
-                               const float *d_ab, const float *d_out, hipStream_t stream);
+                               const float *d_act, const float *d_wrow, const float *d_out, hipStream_t stream);
 
 // A ragged tail of up to 64 rows past a multiple of the 256-row tile is peeled off into a second, tiny launch (see
 // launch_gemm_bf16): M = 16 x 1025 = 64 x 256 + 16 would otherwise cost a whole extra round of workgroups.
 int launch_gemm_fp8(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
-                    const float *lam, const float *R, float *Y2, float ab_scale, float out_inv_scale, const float *d_ab,
-                    const float *d_out, hipStream_t stream)
+                    const float *lam, const float *R, float *Y2, float ab_scale, float out_inv_scale, const float *d_act,
+                    const float *d_wrow, const float *d_out, hipStream_t stream)
 {
     const int rem = M % 256;
     const long nbn = (N + 255) / 256, full = ((long)M / 256 + 1) * nbn, mainp = ((long)M / 256) * nbn;
     if (rem != 0 && rem <= 64 && M > 256 && (full + 255) / 256 > (mainp + 255) / 256) {   // peel only when it saves a round
         const int main_rows = M - rem;
         const size_t out_elt = epi == EPI_SCALE_RESID ? 4 : epi == EPI_BIAS_GELU ? 1 : 2;
-        int rc = launch_gemm_fp8_one(A, lda, W, bias, Y, ldy, main_rows, N, K, epi, lam, R, Y2, ab_scale, out_inv_scale, d_ab, d_out, stream);
+        int rc = launch_gemm_fp8_one(A, lda, W, bias, Y, ldy, main_rows, N, K, epi, lam, R, Y2, ab_scale, out_inv_scale, d_act, d_wrow, d_out, stream);
         if (rc != LDIT_OK) return rc;
         const char *At = static_cast<const char *>(A) + (size_t)main_rows * lda;
         char *Yt = static_cast<char *>(Y) + (size_t)main_rows * ldy * out_elt;
         return launch_gemm_fp8_one(At, lda, W, bias, Yt, ldy, rem, N, K, epi, lam, R ? R + (size_t)main_rows * ldy : nullptr,
-                                   Y2 ? Y2 + (size_t)main_rows * ldy : nullptr, ab_scale, out_inv_scale, d_ab, d_out, stream);
+                                   Y2 ? Y2 + (size_t)main_rows * ldy : nullptr, ab_scale, out_inv_scale, d_act, d_wrow, d_out, stream);
     }
-    return launch_gemm_fp8_one(A, lda, W, bias, Y, ldy, M, N, K, epi, lam, R, Y2, ab_scale, out_inv_scale, d_ab, d_out, stream);
+    return launch_gemm_fp8_one(A, lda, W, bias, Y, ldy, M, N, K, epi, lam, R, Y2, ab_scale, out_inv_scale, d_act, d_wrow, d_out, stream);
 }
 
 static int launch_gemm_fp8_one(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K,
                                int epi, const float *lam, const float *R, float *Y2, float ab_scale, float out_inv_scale,
-                               const float *d_ab, const float *d_out, hipStream_t stream)
+                               const float *d_act, const float *d_wrow, const float *d_out, hipStream_t stream)
 {
     if (M <= 0 || N <= 0 || K <= 0) return fail(LDIT_EINVAL, "gemm_fp8: empty problem");
     if (K % BKE) return fail(LDIT_EUNSUPPORTED, "gemm_fp8: K=%d must be a multiple of %d", K, BKE);
@@ -511,7 +538,7 @@ static int launch_gemm_fp8_one(const void *A, int lda, const void *W, const floa
     GemmArgs8 a{};
     a.A = static_cast<const unsigned char *>(A); a.W = static_cast<const unsigned char *>(W); a.Y = Y; a.Y2 = Y2;
     a.bias = bias; a.lam = lam; a.R = R; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldy = ldy;
-    a.ab_scale = ab_scale; a.out_inv_scale = out_inv_scale; a.d_ab = d_ab; a.d_out = d_out;
+    a.ab_scale = ab_scale; a.out_inv_scale = out_inv_scale; a.d_act = d_act; a.d_wrow = d_wrow; a.d_out = d_out;
     static const int direct = [] { const char *e = getenv("LDIT_GEMM_DIRECT_EPILOGUE"); return (e && *e == '1') ? 1 : 0; }();
     a.direct_epi = direct;
     switch (epi) {
@@ -529,6 +556,16 @@ int launch_quant_fp8(const float *src, void *dst, size_t n, float inv_scale, con
     if (n == 0) return LDIT_OK;
     hipLaunchKernelGGL(quant_fp8, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream, src,
                        static_cast<unsigned char *>(dst), n, inv_scale, d_scale);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+int launch_quant_rows_fp8(const float *W, void *dst, float *scales, int N, int K, hipStream_t stream)
+{
+    if (N <= 0 || K <= 0 || (K & 3)) return fail(LDIT_EINVAL, "quant_rows_fp8: bad shape %d x %d", N, K);
+    if (!W || !dst || !scales || !aligned16(W)) return fail(LDIT_EINVAL, "quant_rows_fp8: null or misaligned operand");
+    hipLaunchKernelGGL(quant_rows_fp8, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, W, static_cast<unsigned char *>(dst),
+                       scales, N, K);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }

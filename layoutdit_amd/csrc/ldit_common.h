@@ -121,11 +121,13 @@ int launch_preprocess(const float *const *images, const int *heights, const int 
 int launch_gemm_bf16(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
                      const float *lam, const float *R, float *Y2, hipStream_t stream);
 int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream);
-// fp8: d_ab (device, 2 floats: activation scale, weight scale) and d_out (device, 1 float: scale of the fp8 output) take
-// precedence over the host values ab_scale / out_inv_scale when non-null.
+// fp8: the per-tensor part of the accumulator's dequantisation is d_act[0] when d_act is non-null (device), else the host
+// value ab_scale; d_wrow (device, [N], optional) multiplies per-output-channel weight scales onto it; d_out (device, 1
+// float: scale of the fp8 output) overrides out_inv_scale.
 int launch_gemm_fp8(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
-                    const float *lam, const float *R, float *Y2, float ab_scale, float out_inv_scale, const float *d_ab,
-                    const float *d_out, hipStream_t stream);
+                    const float *lam, const float *R, float *Y2, float ab_scale, float out_inv_scale, const float *d_act,
+                    const float *d_wrow, const float *d_out, hipStream_t stream);
+int launch_quant_rows_fp8(const float *W, void *dst, float *scales, int N, int K, hipStream_t stream);
 int launch_quant_fp8(const float *src, void *dst, size_t n, float inv_scale, const float *d_scale, hipStream_t stream);
 int launch_amax_f32(const float *src, size_t n, float *out, bool accumulate, hipStream_t stream);
 int launch_amax_to_scale(float *p, int n, hipStream_t stream);   // p[i] = max(p[i], tiny) / 448

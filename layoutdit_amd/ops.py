@@ -171,11 +171,26 @@ def quant_fp8(x: torch.Tensor, scale: float) -> torch.Tensor:
     return out
 
 
+def quant_rows_fp8(w: torch.Tensor):
+    """Per-output-channel weight quantisation: ``(codes [N, K] fp8 e4m3, scales [N] fp32)`` with
+    ``w[n, :] ~= scales[n] * codes[n, :]``."""
+    lib = _lib.load()
+    w = _req(w, "w")
+    N, K = w.shape
+    codes = torch.empty((N, K), device=w.device, dtype=torch.float8_e4m3fn)
+    scales = torch.empty(N, device=w.device, dtype=torch.float32)
+    _lib.check(lib.ldit_quant_rows_f32_fp8(_ptr(w), _ptr(codes), _ptr(scales), N, K, _stream()))
+    return codes, scales
+
+
 def linear_fp8(x: torch.Tensor, weight: torch.Tensor, ab_scale: float, bias: Optional[torch.Tensor] = None,
                epilogue: int = _lib.EPI_BIAS, lam: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-               out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out_scale: float = 1.0) -> torch.Tensor:
-    """fp8 MFMA GEMM: ``x`` [M, K], ``weight`` [N, K] fp8 e4m3 codes, ``ab_scale`` = scale_x * scale_w; bf16 result for the
-    bias epilogue, fp8 codes of ``gelu(.) / out_scale`` for the GELU epilogue, fp32 for the scale+residual epilogue."""
+               out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None, out_scale: float = 1.0,
+               w_scales: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp8 MFMA GEMM: ``x`` [M, K], ``weight`` [N, K] fp8 e4m3 codes; the accumulator is multiplied by ``ab_scale`` (=
+    scale_x * scale_w per tensor) or by ``ab_scale * w_scales[n]`` (``ab_scale`` = scale_x, ``w_scales`` per output
+    channel); bf16 result for the bias epilogue, fp8 codes of ``gelu(.) / out_scale`` for the GELU epilogue, fp32 for the
+    scale+residual epilogue."""
     lib = _lib.load()
     for t, n in ((x, "x"), (weight, "weight")):
         if not t.is_cuda or t.dtype != torch.float8_e4m3fn or not t.is_contiguous():
@@ -185,11 +200,12 @@ def linear_fp8(x: torch.Tensor, weight: torch.Tensor, ab_scale: float, bias: Opt
     if out is None:
         dt = {_lib.EPI_BIAS: torch.bfloat16, _lib.EPI_BIAS_GELU: torch.float8_e4m3fn, _lib.EPI_SCALE_RESID: torch.float32}[epilogue]
         out = torch.empty((M, N), device=x.device, dtype=dt)
-    for t, n in ((bias, "bias"), (lam, "lam"), (residual, "residual"), (out2, "out2")):
+    for t, n in ((bias, "bias"), (lam, "lam"), (residual, "residual"), (out2, "out2"), (w_scales, "w_scales")):
         if t is not None:
             _req(t, n)
     _lib.check(lib.ldit_linear_fp8(_ptr(x), K, _ptr(weight), _ptr(bias), _ptr(out), N, M, N, K, epilogue, _ptr(lam),
-                                   _ptr(residual), _ptr(out2), float(ab_scale), 1.0 / float(out_scale), _stream()))
+                                   _ptr(residual), _ptr(out2), float(ab_scale), 1.0 / float(out_scale), _ptr(w_scales),
+                                   _stream()))
     return out
 
 

@@ -119,7 +119,7 @@ def test_state_dict_layouts_round_trip():
 
 def test_low_precision_builds_keep_the_checkpoint_surface_and_size_their_buffers():
     """bf16 / fp8 builds: same state_dict keys as fp32 (the fp8 activation scales are a non-persistent buffer), packed
-    block = 2-byte / 1-byte matrices (+ 8 scale floats per layer for fp8), fp8 geometry limits reported by the library."""
+    block = 2-byte / 1-byte matrices (fp8: + 8 activation-scale floats and one weight scale per output channel per layer), fp8 geometry limits reported by the library."""
     lib = _lib.load()
     cfg = cfgs.vit_base()
     keys = set(DiTEncoder(cfg).state_dict())
@@ -135,7 +135,7 @@ def test_low_precision_builds_keep_the_checkpoint_surface_and_size_their_buffers
     lc.dtype = _lib.DTYPE_BF16
     assert lib.ldit_packed_bytes(C.byref(lc)) == f32 - 2 * mats
     lc.dtype = _lib.DTYPE_FP8
-    assert lib.ldit_packed_bytes(C.byref(lc)) == f32 - 3 * mats + 12 * 32
+    assert lib.ldit_packed_bytes(C.byref(lc)) == f32 - 3 * mats + 12 * (32 + 4 * (3 * 768 + 768 + 3072 + 768))   # + scales
     lt = _cfg(cfgs.vit_tiny())                       # hidden 192: not a multiple of the fp8 k-tile
     lt.dtype = _lib.DTYPE_FP8
     assert lib.ldit_packed_bytes(C.byref(lt)) == 0 and "multiples of 128" in lib.ldit_last_error().decode()

@@ -208,3 +208,36 @@ def test_fp8_forward_ragged_rectangular_and_graph_replay():
         torch.cuda.synchronize()
     for a, b in zip(static_out, eager):
         assert torch.equal(a, b)
+
+
+def test_per_channel_weight_scales_rescue_small_rows():
+    """e4m3 is a floating-point format (normal range 2^-6 .. 448), so a per-tensor scale only hurts once rows differ by
+    more than ~4 orders of magnitude: then the small rows sink into the subnormals, while one scale per output channel
+    keeps three mantissa bits for every row.  Also pins ldit_quant_rows_f32_fp8 against torch's cast."""
+    M, N, K = 300, 256, 256
+    x = _rand(21, M, K)
+    w = _rand(22, N, K, scale=0.02)
+    w[::16] *= 3.0e4                                         # 16 dominant rows
+    b = _rand(23, N, scale=0.1)
+    sx = float(np.abs(x).max()) / 448.0
+    xq, xv = _codes(x, sx)
+    ref = oracle.linear(x, w, b)
+    # per tensor
+    sw = float(np.abs(w).max()) / 448.0
+    wq_t, _ = _codes(w, sw)
+    y_t = ops.linear_fp8(xq.to(DEV), wq_t.to(DEV), sx * sw, torch.from_numpy(b).to(DEV)).float().cpu().numpy()
+    # per output channel
+    codes, scales = ops.quant_rows_fp8(torch.from_numpy(w).to(DEV))
+    s_ref = np.abs(w).max(axis=1) / np.float32(448.0)
+    np.testing.assert_allclose(scales.cpu().numpy(), s_ref, rtol=1e-6)
+    want = (torch.from_numpy(w) * (1.0 / torch.from_numpy(scales.cpu().numpy()))[:, None]).clamp(-448.0, 448.0).to(F8)
+    assert (codes.cpu().view(torch.uint8) != want.view(torch.uint8)).float().mean().item() < 1e-3   # 1/s vs division ties
+    y_c = ops.linear_fp8(xq.to(DEV), codes, sx, torch.from_numpy(b).to(DEV), w_scales=scales).float().cpu().numpy()
+    small = np.ones(N, bool)
+    small[::16] = False
+    err_t, err_c = rel_l2(y_t[:, small], ref[:, small]), rel_l2(y_c[:, small], ref[:, small])
+    assert err_c < 0.08 and err_t > 3 * err_c, (err_t, err_c)
+    assert rel_l2(y_c[:, ~small], ref[:, ~small]) < 0.08
+    # exactness of the per-channel path itself: oracle on the dequantised operands
+    deq = codes.float().cpu().numpy() * scales.cpu().numpy()[:, None]
+    assert rel_l2(y_c, oracle.linear(xv * np.float32(sx), deq, b)) < 3e-3
