@@ -170,3 +170,23 @@ def test_forward_bf16_is_batch_invariant():
         small = m(x[40:42]).hidden_states
     for t in cfg.taps:
         assert torch.equal(big[t][40:42], small[t]), t
+
+
+def test_forward_bf16_vs_cpu_bf16_autocast_of_the_oracle():
+    """besides the fp32 oracle, compare with the oracle run in bf16 on the CPU - here the torch-ops
+    restatement under ``torch.autocast("cpu", bfloat16)``, i.e. what the reference's BeitModel computes under the autocast
+    its trainer uses (linears and attention in bf16, LayerNorm and the LayerScale residual adds in fp32).  Two bf16
+    pipelines with different rounding points: gate at 1e-2 rel-L2 per tap."""
+    from layoutdit_amd import config as cfgs
+    from layoutdit_amd.modeling import DiTEncoder
+    from oracle.vit_oracle_torch import TorchOracle
+    cfg = cfgs.vit_tiny()
+    w = synth.synth_weights(cfg, 1)
+    x = synth.synth_images(2, 224, 224, seed=1234)
+    m = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(w).to(DEV).eval()
+    with torch.no_grad():
+        out = m(torch.from_numpy(x).to(DEV))
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ref = TorchOracle(cfg, w).forward(x)
+    for t, r in zip(cfg.taps, ref):
+        assert rel_l2(out.hidden_states[t].cpu().numpy(), r.float().numpy()) < 1e-2, t

@@ -152,6 +152,21 @@ def test_error_behaviour():
     assert m(torch.zeros(1, 3, 64, 64, device=DEV)).hidden_states[3] is not None   # frozen backbone in train mode is fine
 
 
+def test_half_precision_inputs_are_widened_and_outputs_follow_the_input_dtype():
+    """The reference's trainer feeds ``.half()`` images (ref src/layoutdit/training/trainer.py:155): the module widens
+    them to fp32 for the kernels and hands the hidden states back in the input's dtype."""
+    cfg = cfgs.vit_micro()
+    m, _ = _model(cfg, 7)
+    x = torch.from_numpy(synth.synth_images(2, 64, 64, seed=3)).to(DEV)
+    with torch.no_grad():
+        ref = m(x.half().float()).hidden_states[3]
+        for dt in (torch.float16, torch.bfloat16):
+            out = m(x.half().to(dt)).hidden_states[3]
+            assert out.dtype == dt
+            assert torch.equal(out, ref.to(dt)) or dt == torch.bfloat16     # bf16 re-rounds the fp16-exact pixels
+            assert torch.allclose(out.float(), ref, rtol=2e-2, atol=2e-2)
+
+
 def test_backbone_feature_maps_vs_golden(golden_dir):
     """DiTBackbone.forward -> {p2..p5} (ref src/layoutdit/modeling/dit_backbone.py:38-62)."""
     g0 = np.load(os.path.join(golden_dir, "g0_micro.npz"))
