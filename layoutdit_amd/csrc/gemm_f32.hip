@@ -365,6 +365,9 @@ int launch_gemm(const GemmArgs &a, int epi, int amode, hipStream_t stream)
 {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return fail(LDIT_EINVAL, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     if (a.K % BK) return fail(LDIT_EUNSUPPORTED, "gemm: K=%d must be a multiple of %d", a.K, BK);
+    // the kernels keep the offset INSIDE one block tile (<= 320 rows) as a 32-bit byte offset: 320 * 2^21 * 4 < 2^32
+    if (amode == A_ROWMAJOR && (a.lda >= (1 << 21) || a.K >= (1 << 21)))
+        return fail(LDIT_EUNSUPPORTED, "gemm: row stride lda=%d / K=%d must be below 2^21 elements", a.lda, a.K);
     if (!a.A || !a.W || !a.Y) return fail(LDIT_EINVAL, "gemm: null operand");
     if (!aligned16(a.A) || !aligned16(a.W) || (a.lda & 3)) return fail(LDIT_EINVAL, "gemm: operands must be 16-byte aligned");
     if (amode == A_PATCH) {

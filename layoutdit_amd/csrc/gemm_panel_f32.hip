@@ -183,7 +183,11 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
     }
     const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
 
-    // ---- DMA sources: this wave moves pieces wave + 4u (8 rows x 128 B each); 32-bit element offsets -----------------
+    // ---- DMA sources: this wave moves pieces wave + 4u (8 rows x 128 B each).  Row-major operands: the tile origin
+    // (m0 * lda, n0 * K) goes into the 64-bit wave-uniform base, only the offset INSIDE the tile (< 304 rows) is kept in
+    // 32 bits - as a byte offset it stays below 2^32 for any row stride the host admits (ldit_linear_f32: lda, K < 2^21),
+    // so M * lda may be anything the 2^31-element host limit allows.  Patch mode keeps 32-bit ELEMENT offsets into the
+    // image batch (host limit: B * in_ch * H * W < 2^31).
     unsigned src[NLD];
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
@@ -197,20 +201,22 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
                 const int gy = pi / p.gw, gx = pi - gy * p.gw;
                 src[u] = (unsigned)b * (unsigned)p.lda + (unsigned)(gy * p.patch * p.img_w + gx * p.patch);
             } else {
-                src[u] = ((unsigned)gm * (unsigned)p.lda + c * 4) * 4u;      // BYTE offset (row-major operands)
+                src[u] = ((unsigned)(gm - m0) * (unsigned)p.lda + c * 4) * 4u;      // BYTE offset inside the tile
             }
         } else {
             int gn = n0 + row - BM;
             gn = gn < p.N ? gn : p.N - 1;
-            src[u] = ((unsigned)gn * (unsigned)p.K + c * 4) * 4u;              // BYTE offset
+            src[u] = ((unsigned)(gn - n0) * (unsigned)p.K + c * 4) * 4u;            // BYTE offset inside the tile
         }
     }
+    const float *a_tile = AMODE == A_PATCH ? p.A : p.A + (size_t)m0 * (size_t)p.lda;
+    const float *w_tile = p.W + (size_t)n0 * (size_t)p.K;
     auto issue = [&](int stage, int k0) {
         char *base = smem + stage * STAGE_BYTES;
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int piece = wave + 4 * u;
-            const float *opnd = 8 * piece < BM ? p.A : p.W;
+            const float *opnd = 8 * piece < BM ? a_tile : w_tile;
             const float *g;
             if (AMODE == A_PATCH && 8 * piece < BM) {
                 const int row = 8 * piece + (lane >> 3);

@@ -49,12 +49,15 @@ class DiTBackbone(nn.Module):
         hs = self.dit(x, taps=self.layer_idxs).hidden_states
         feats = OrderedDict()
         for i, (idx, scale) in enumerate(zip(self.layer_idxs, self.scales), start=2):
+            h = hs[idx]
             if scale == 1.0:
                 # zero-copy, physically NHWC view - exactly what the reference hands to the FPN (dit_backbone.py:52-54)
-                t = hs[idx][:, 1:, :].permute(0, 2, 1).reshape(B, self.hidden_size, Gh, Gw) \
-                    if not hs[idx].is_contiguous() else \
-                    hs[idx][:, 1:, :].permute(0, 2, 1).unflatten(2, (Gh, Gw))
+                t = h[:, 1:, :].permute(0, 2, 1).unflatten(2, (Gh, Gw))
             else:
-                t = ops.tap_to_map(hs[idx].float().contiguous(), Gh, Gw, scale).to(hs[idx].dtype)
+                # the encoder returns fp32 contiguous taps for fp32 input: no host-side copies on that path
+                src = h if (h.dtype == torch.float32 and h.is_contiguous()) else h.float().contiguous()
+                t = ops.tap_to_map(src, Gh, Gw, scale)
+                if t.dtype != h.dtype:
+                    t = t.to(h.dtype)
             feats[f"p{i}"] = t
         return feats

@@ -13,8 +13,27 @@ import torch
 from . import _lib
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _device(*tensors) -> torch.device:
+    """The one device every tensor argument lives on (None entries skipped); mixed devices are an error."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError(f"tensor arguments live on different devices ({dev} and {t.device})")
+    if dev is None or dev.type != "cuda":
+        raise ValueError("expected tensors on the GPU (libldit_hip has no CPU path)")
+    return dev
+
+
+def _launch(dev: torch.device, fn, *args) -> None:
+    """Call one C entry point with the stream of the TENSORS' device (not of whatever device is current), with that
+    device made current for the launch: the library enqueues on the stream it is handed and HIP launches on the
+    current device, so both must be the operands' own."""
+    with torch.cuda.device(dev):
+        _lib.check(fn(*args, torch.cuda.current_stream(dev).cuda_stream))
 
 
 def _req(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -46,8 +65,8 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     for t, n in ((bias, "bias"), (lam, "lam"), (residual, "residual"), (out, "out"), (out2, "out2")):
         if t is not None:
             _req(t, n)
-    _lib.check(lib.ldit_linear_f32(_ptr(x), K, _ptr(weight), _ptr(bias), _ptr(out), N, M, N, K, epilogue, _ptr(lam),
-                                   _ptr(residual), _ptr(out2), _stream()))
+    _launch(_device(x, weight, bias, lam, residual, out, out2), lib.ldit_linear_f32, _ptr(x), K, _ptr(weight), _ptr(bias), _ptr(out), N, M, N, K, epilogue, _ptr(lam),
+                                   _ptr(residual), _ptr(out2))
     return out
 
 
@@ -57,7 +76,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     C = x.shape[-1]
     rows = x.numel() // C
     y = torch.empty_like(x)
-    _lib.check(lib.ldit_layernorm_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), rows, C, eps, _stream()))
+    _launch(_device(x, gamma, beta), lib.ldit_layernorm_f32, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), rows, C, eps)
     return y
 
 
@@ -70,8 +89,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     B, N, HD = q.shape
     D = HD // heads
     o = torch.empty((B, N, HD), device=q.device, dtype=torch.float32)
-    _lib.check(lib.ldit_attention_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, N, heads, D, q.stride(1), k.stride(1),
-                                      v.stride(1), HD, float(D ** -0.5 if scale is None else scale), _stream()))
+    _launch(_device(q, k, v), lib.ldit_attention_f32, _ptr(q), _ptr(k), _ptr(v), _ptr(o), B, N, heads, D, q.stride(1), k.stride(1),
+                                      v.stride(1), HD, float(D ** -0.5 if scale is None else scale))
     return o
 
 
@@ -84,8 +103,8 @@ def embed(x: torch.Tensor, patch_w: torch.Tensor, patch_b: torch.Tensor, cls: to
     Cc = patch_w.shape[0]
     T = (H // patch) * (W // patch) + 1
     out = torch.empty((B, T, Cc), device=x.device, dtype=torch.float32)
-    _lib.check(lib.ldit_embed_f32(_ptr(x), _ptr(patch_w), _ptr(patch_b), _ptr(cls), _ptr(pos), _ptr(out), B, in_ch, H, W,
-                                  patch, Cc, _stream()))
+    _launch(_device(x, patch_w, patch_b, cls, pos), lib.ldit_embed_f32, _ptr(x), _ptr(patch_w), _ptr(patch_b), _ptr(cls), _ptr(pos), _ptr(out), B, in_ch, H, W,
+                                  patch, Cc)
     return out
 
 
@@ -96,7 +115,7 @@ def tap_to_map(tap: torch.Tensor, gh: int, gw: int, scale: float) -> torch.Tenso
     if T != gh * gw + 1:
         raise ValueError(f"tap has {T} tokens, grid {gh}x{gw} needs {gh * gw + 1}")
     out = torch.empty((B, Cc, int(gh * scale), int(gw * scale)), device=tap.device, dtype=torch.float32)
-    _lib.check(lib.ldit_tap_to_map_f32(_ptr(tap), _ptr(out), B, gh, gw, Cc, float(scale), _stream()))
+    _launch(_device(tap), lib.ldit_tap_to_map_f32, _ptr(tap), _ptr(out), B, gh, gw, Cc, float(scale))
     return out
 
 
@@ -115,7 +134,7 @@ def preprocess(images: Sequence[torch.Tensor], size: int = 224, mean: float = 0.
     ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in imgs])
     hs = (C.c_int32 * B)(*[t.shape[1] for t in imgs])
     ws = (C.c_int32 * B)(*[t.shape[2] for t in imgs])
-    _lib.check(lib.ldit_preprocess_f32(ptrs, hs, ws, B, ch, mean, std, size, size, _ptr(out), _stream()))
+    _launch(_device(*imgs), lib.ldit_preprocess_f32, ptrs, hs, ws, B, ch, mean, std, size, size, _ptr(out))
     return out
 
 
@@ -124,7 +143,7 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     x = _req(x, "x")
     out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
-    _lib.check(lib.ldit_cast_f32_bf16(_ptr(x), _ptr(out), x.numel(), _stream()))
+    _launch(_device(x), lib.ldit_cast_f32_bf16, _ptr(x), _ptr(out), x.numel())
     return out
 
 
@@ -145,8 +164,8 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     for t, n in ((bias, "bias"), (lam, "lam"), (residual, "residual"), (out2, "out2")):
         if t is not None:
             _req(t, n)
-    _lib.check(lib.ldit_linear_bf16(_ptr(x), K, _ptr(weight), _ptr(bias), _ptr(out), N, M, N, K, epilogue, _ptr(lam),
-                                    _ptr(residual), _ptr(out2), _stream()))
+    _launch(_device(x, weight, bias, lam, residual, out, out2), lib.ldit_linear_bf16, _ptr(x), K, _ptr(weight), _ptr(bias), _ptr(out), N, M, N, K, epilogue, _ptr(lam),
+                                    _ptr(residual), _ptr(out2))
     return out
 
 
@@ -158,7 +177,7 @@ def amax(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     x = _req(x, "x")
     out = torch.empty(1, device=x.device, dtype=torch.float32)
-    _lib.check(lib.ldit_amax_f32(_ptr(x), x.numel(), _ptr(out), _stream()))
+    _launch(_device(x), lib.ldit_amax_f32, _ptr(x), x.numel(), _ptr(out))
     return out
 
 
@@ -167,7 +186,7 @@ def quant_fp8(x: torch.Tensor, scale: float) -> torch.Tensor:
     lib = _lib.load()
     x = _req(x, "x")
     out = torch.empty(x.shape, device=x.device, dtype=torch.float8_e4m3fn)
-    _lib.check(lib.ldit_quant_f32_fp8(_ptr(x), _ptr(out), x.numel(), 1.0 / float(scale), _stream()))
+    _launch(_device(x), lib.ldit_quant_f32_fp8, _ptr(x), _ptr(out), x.numel(), 1.0 / float(scale))
     return out
 
 
@@ -179,7 +198,7 @@ def quant_rows_fp8(w: torch.Tensor):
     N, K = w.shape
     codes = torch.empty((N, K), device=w.device, dtype=torch.float8_e4m3fn)
     scales = torch.empty(N, device=w.device, dtype=torch.float32)
-    _lib.check(lib.ldit_quant_rows_f32_fp8(_ptr(w), _ptr(codes), _ptr(scales), N, K, _stream()))
+    _launch(_device(w), lib.ldit_quant_rows_f32_fp8, _ptr(w), _ptr(codes), _ptr(scales), N, K)
     return codes, scales
 
 
@@ -203,9 +222,8 @@ def linear_fp8(x: torch.Tensor, weight: torch.Tensor, ab_scale: float, bias: Opt
     for t, n in ((bias, "bias"), (lam, "lam"), (residual, "residual"), (out2, "out2"), (w_scales, "w_scales")):
         if t is not None:
             _req(t, n)
-    _lib.check(lib.ldit_linear_fp8(_ptr(x), K, _ptr(weight), _ptr(bias), _ptr(out), N, M, N, K, epilogue, _ptr(lam),
-                                   _ptr(residual), _ptr(out2), float(ab_scale), 1.0 / float(out_scale), _ptr(w_scales),
-                                   _stream()))
+    _launch(_device(x, weight, bias, lam, residual, out, out2, w_scales), lib.ldit_linear_fp8, _ptr(x), K, _ptr(weight), _ptr(bias), _ptr(out), N, M, N, K, epilogue, _ptr(lam),
+                                   _ptr(residual), _ptr(out2), float(ab_scale), 1.0 / float(out_scale), _ptr(w_scales))
     return out
 
 
@@ -218,6 +236,6 @@ def attention_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int
     B, N, HD = q.shape
     D = HD // heads
     o = torch.empty((B, N, HD), device=q.device, dtype=torch.bfloat16)
-    _lib.check(lib.ldit_attention_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, N, heads, D, q.stride(1), k.stride(1),
-                                       v.stride(1), HD, float(D ** -0.5 if scale is None else scale), _stream()))
+    _launch(_device(q, k, v), lib.ldit_attention_bf16, _ptr(q), _ptr(k), _ptr(v), _ptr(o), B, N, heads, D, q.stride(1), k.stride(1),
+                                       v.stride(1), HD, float(D ** -0.5 if scale is None else scale))
     return o

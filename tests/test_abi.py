@@ -83,6 +83,25 @@ def test_null_and_misaligned_arguments_fail_before_any_launch():
     assert rc == _lib.LDIT_EUNSUPPORTED
 
 
+def test_gemm_index_space_guards_at_the_boundary():
+    """Guard arithmetic of ldit_linear_f32: operands are indexed with 32-bit ELEMENT offsets from the matrix
+    origin (limit 2^31 elements) and the panel kernel keeps a 32-bit BYTE offset inside one 304-row tile (limit: row
+    stride < 2^21 elements); ViT-L 512x512 at batch 256..511 (M * lda in [2^30, 2^31)) must be ADMITTED - the tile
+    origin travels in the 64-bit base - and everything past the limits refused.  No call here can reach a launch: the
+    admitted cases carry a misaligned pointer that a LATER host-side check rejects (so the index guard was passed)."""
+    lib = _lib.load()
+    big_m, lda = 262400, 4096                                   # M * lda = 1.07e9: in [2^30, 2^31)
+    assert 2 ** 30 <= big_m * lda < 2 ** 31
+    rc = lib.ldit_linear_f32(16, lda, 16, None, 8, 1024, big_m, 1024, lda, 0, None, None, None, None)   # Y misaligned
+    assert rc == _lib.LDIT_EINVAL and b"misaligned" in lib.ldit_last_error()
+    rc = lib.ldit_linear_f32(16, lda, 16, None, 16, 1024, 2 ** 31 // lda, 1024, lda, 0, None, None, None, None)
+    assert rc == _lib.LDIT_EUNSUPPORTED and b"2^31" in lib.ldit_last_error()
+    rc = lib.ldit_linear_f32(16, 2 ** 21, 16, None, 16, 32, 8, 32, 32, 0, None, None, None, None)
+    assert rc == _lib.LDIT_EUNSUPPORTED and b"2^21" in lib.ldit_last_error()
+    rc = lib.ldit_linear_f32(8, 2 ** 21 - 4, 16, None, 16, 32, 8, 32, 32, 0, None, None, None, None)   # X misaligned
+    assert rc == _lib.LDIT_EINVAL and b"16-byte aligned" in lib.ldit_last_error()
+
+
 def test_module_surface_matches_what_the_reference_touches():
     cfg = cfgs.vit_tiny()
     m = DiTEncoder(cfg)
@@ -158,3 +177,32 @@ def test_flops_formula_matches_baseline_md():
     assert cfgs.vit_base().flops_per_image() == 2 * 17_563_060_224
     assert cfgs.vit_tiny().flops_per_image() == 2 * 1_253_491_200
     assert cfgs.vit_large().flops_per_image(512, 512) == 2 * 361_985_261_568
+
+
+def test_ops_wrappers_take_device_and_stream_from_their_tensors():
+    """no wrapper may launch on `torch.cuda.current_stream()` of whatever device happens to be current.
+    Structural check (there is one GPU at most where tests run): every public function of layoutdit_amd.ops that
+    reaches the library does so through `_launch(_device(<its tensors>), ...)`, and `_launch` enters
+    `torch.cuda.device(dev)` and asks for `current_stream(dev)`."""
+    import ast
+    import inspect
+    from layoutdit_amd import ops
+    tree = ast.parse(inspect.getsource(ops))
+    funcs = {n.name: n for n in tree.body if isinstance(n, ast.FunctionDef)}
+    src_launch = ast.get_source_segment(inspect.getsource(ops), funcs["_launch"])
+    assert "torch.cuda.device(dev)" in src_launch and "current_stream(dev)" in src_launch
+    lib_calls = 0
+    for name, fn in funcs.items():
+        for node in ast.walk(fn):
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "current_stream":
+                assert name == "_launch" and node.args, f"{name} asks for a stream without naming the device"
+            if isinstance(node, ast.Attribute) and node.attr.startswith("ldit_") and name != "_launch":
+                lib_calls += 1
+                # the attribute must be an argument of a _launch(_device(...), lib.ldit_x, ...) call
+                ok = any(isinstance(c, ast.Call) and getattr(c.func, "id", "") == "_launch" and node in c.args
+                         and isinstance(c.args[0], ast.Call) and getattr(c.args[0].func, "id", "") == "_device"
+                         for c in ast.walk(fn))
+                assert ok, f"{name}: {node.attr} is not called through _launch(_device(...), ...)"
+    assert lib_calls >= 13
+    with pytest.raises(ValueError, match="GPU"):
+        ops._device(torch.zeros(1))

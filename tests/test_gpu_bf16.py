@@ -98,26 +98,19 @@ def test_attention_bf16_on_fused_views_and_large_logits():
     assert rel_l2(o, ref) < 6e-3
 
 
-@pytest.mark.parametrize("geom,size,B", [("tiny", 224, 2), ("base", 224, 2), ("large", 512, 1)])
+@pytest.mark.parametrize("geom,size,B", [("tiny", 224, 2), ("base", 224, 2)])
 def test_forward_bf16_vs_fp32_oracle(geom, size, B):
-    """Whole path in bf16 against the fp32 oracle: SURVEY.md 8(d) gate rel-L2 <= 2e-2 per tap (measured ~3e-3)."""
+    """Whole path in bf16 against the fp32 oracle: SURVEY.md 8(d) gate rel-L2 <= 2e-2 per tap (measured ~3e-3).
+    The ViT-L 512x512 case (configs[3]) is pinned to the HF golden in tests/test_gpu_lowp_pinning.py."""
     from layoutdit_amd import config as cfgs
     from layoutdit_amd.modeling import DiTEncoder
-    from tests.util import resample_pos
     cfg = cfgs.GEOMETRIES[geom]()
     w = synth.synth_weights(cfg, 1)
     m = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(w).to(DEV).eval()
     x = synth.synth_images(B, size, size, seed=1234)
     with torch.no_grad():
         out = m(torch.from_numpy(x).to(DEV))
-    if geom == "large":
-        # the 24-layer, N = 1025 oracle run takes minutes on the host: compare with the fp32 HIP path instead, which
-        # tests/test_gpu_forward.py pins to the HF golden for this exact input
-        m32 = DiTEncoder(cfg).load_numpy(w).to(DEV).eval()
-        with torch.no_grad():
-            ref = [m32(torch.from_numpy(x).to(DEV)).hidden_states[t].cpu().numpy() for t in cfg.taps]
-    else:
-        ref, _ = oracle.vit_forward(cfg, w, x)
+    ref, _ = oracle.vit_forward(cfg, w, x)
     for t, r in zip(cfg.taps, ref):
         h = out.hidden_states[t]
         assert h.dtype == torch.float32
