@@ -1,25 +1,38 @@
 #!/usr/bin/env python3
-"""Headline benchmark: images/sec of the ViT-B/16 224x224 bs=64 fp32 encoder forward (BASELINE.json metric/config 2)
-on N MI355X GPUs, one process per GPU, batch-sharded replicas (weak scaling: 64 images per GPU, no collective on the
-data path).
+"""Benchmarks of the hot path on N MI355X GPUs, one process per GPU, batch-sharded replicas (weak scaling).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,3,4}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step = one forward of the hot path (``self.dit(x).hidden_states`` -> taps 4/6/8/12) over one 64-image synthetic
-batch already resident in HBM.  Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     - the dominant kernel family (the fp32 MFMA GEMM): algorithmic FLOPs / HIP-event time per launch,
-                 measured live in a second K-step pass with events on the launch stream, against the 157.3 TFLOP/s
-                 fp32-matrix peak of gfx950 (MI355X_MICROARCH.md).
-  cpu_baseline - (N = 1 only) the same forward on the host cores: the torch-ops restatement in oracle/ (the ATen CPU
-                 kernels the reference's HF BeitModel path executes), on a bounded sample of the same workload.
+`--config` selects a BASELINE.json `configs[i]` workload (default 1 = the headline metric):
+    1  ViT-B/16 224x224 bs=64/GPU fp32 forward                       images/sec (BASELINE.json `metric`)
+    2  ViT-B/16 224x224 bs=64/GPU bf16 train step: forward + backward + gradient all-reduce (RCCL, N > 1) + fused AdamW
+    3  ViT-L/16 512x512 bs=16/GPU bf16 forward (N = 1025 tokens)
+    4  ViT-B/16 224x224 bs=32/GPU fp8 forward (bs=256 over 8 GPUs)
+(`--model/--size/--batch/--dtype` still override single fields for experiments.)
+
+With `--gpus N > 1` and no WORLD_SIZE in the environment the script launches itself: the parent process (which never
+touches the GPU) starts N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON line and
+exits with the worst child status.  Under torch.distributed.run it simply joins the job it was started in.
+
+A step = one pass of the hot path over one synthetic batch already resident in HBM.  K steps are timed between
+barrier + synchronize brackets (max over ranks); rank 0 prints ONE JSON line.  Extra objects:
+  step_ms      - median / p10 / p90 of the per-step durations from HIP events recorded on the launch stream inside the
+                 same timed region
+  roofline     - the dominant kernel family (the MFMA GEMMs): algorithmic FLOPs / HIP-event time per launch, measured live
+                 in a second K-step pass with events on the launch stream, against the dense MFMA peak of the dtype;
+                 `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_traffic.json,
+                 labelled with the commit they were collected on) or null
+  cpu_baseline - (N = 1, config 1 only) the same forward on the host cores: the torch-ops restatement in oracle/
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,17 +40,65 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np   # noqa: E402
-import torch         # noqa: E402
-
-from layoutdit_amd import config as cfgs, dp, synth           # noqa: E402
-from layoutdit_amd.modeling import DiTEncoder                 # noqa: E402
-
-PEAK_F32_MFMA_TFLOPS = 157.3    # gfx950 dense fp32 matrix peak (spec; 155 measured), MI355X_MICROARCH.md
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}   # dense MFMA peaks (bf16: ~2.5 PF dense, never the 2:1-sparse figure)
-PER_GPU_BATCH = 64
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}   # dense MFMA peaks, MI355X_MICROARCH.md (never the 2:1-sparse figures)
+CONFIGS = {
+    1: dict(model="base", size=224, batch=64, dtype="f32", mode="forward"),
+    2: dict(model="base", size=224, batch=64, dtype="bf16", mode="train"),
+    3: dict(model="large", size=512, batch=16, dtype="bf16", mode="forward"),
+    4: dict(model="base", size=224, batch=32, dtype="fp8", mode="forward"),
+}
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[i]")
+    ap.add_argument("--model", default=None, choices=["micro", "tiny", "base", "large"])
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "fp8"])
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU")
+    ap.add_argument("--mode", default=None, choices=["forward", "train"])
+    ap.add_argument("--cpu-sample", type=int, default=64, help="images timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--no-roofline-pass", action="store_true")
+    args = ap.parse_args(argv)
+    for k, v in CONFIGS[args.config].items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    return args
+
+
+# ---- self-launch -------------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_children(n: int) -> int:
+    """Parent of an N-rank job.  Touches no GPU API (a process that has initialised the GPU must not spawn-and-wait
+    cheaply here, and must never exec): it only forks the interpreter N times with the rendezvous in the environment."""
+    port = free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    worst = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        worst = worst or p.returncode
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return worst
+
+
+# ---- helpers -------------------------------------------------------------------------------------------------------------
 def gemm_flops_per_image(cfg, size: int) -> int:
     P = (size // cfg.patch_size) ** 2
     N = P + 1
@@ -47,14 +108,16 @@ def gemm_flops_per_image(cfg, size: int) -> int:
 
 def pmc_traffic(args):
     """HBM bytes per GEMM launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
-    process).  Only valid for the workload the counters were collected on; otherwise null."""
-    if (args.model, args.size, args.batch, args.dtype) != ("base", 224, 64, "f32"):
-        return None
+    process), with the commit they were measured on.  Only for the exact workload they were collected on; else null."""
+    key = f"{args.mode}:{args.model}:{args.size}:{args.batch}:{args.dtype}"
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_final_traffic.json")) as f:
-            return round(json.load(f)["gemm_hbm_bytes_per_launch"])
+        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+            rec = json.load(f).get(key)
+        if rec:
+            return round(rec["gemm_hbm_bytes_per_launch"]), f"profiles/r02_traffic.json[{key}] profiled@{rec['commit']}"
     except (OSError, KeyError, ValueError):
-        return None
+        pass
+    return None, None
 
 
 def host_cores() -> int:
@@ -72,6 +135,7 @@ def host_cores() -> int:
 
 def cpu_baseline(cfg, weights, x_np, sample: int):
     """Time the torch-ops restatement on the host cores over `sample` images of the same batch."""
+    import torch
     from oracle.vit_oracle_torch import TorchOracle
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -89,24 +153,31 @@ def cpu_baseline(cfg, weights, x_np, sample: int):
                       f"{cores} threads (cgroup quota), best of 3 runs, {best:.2f} s per run"}
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="base", choices=sorted(cfgs.GEOMETRIES))
-    ap.add_argument("--size", type=int, default=224)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "fp8"],
-                    help="f32 = BASELINE configs[1] (headline); bf16 with --model large --size 512 --batch 16 = configs[3]; "
-                         "fp8 with --batch 32 = configs[4] (per-GPU share of bs=256 over 8 GPUs)")
-    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=64, help="images timed on the CPU baseline (0 = skip)")
-    ap.add_argument("--no-roofline-pass", action="store_true")
-    args = ap.parse_args()
+def percentiles(ms):
+    import numpy as np
+    a = np.sort(np.asarray(ms, dtype=np.float64))
+    return {"median": round(float(np.median(a)), 4), "p10": round(float(np.percentile(a, 10)), 4),
+            "p90": round(float(np.percentile(a, 90)), 4), "source": "HIP events on the launch stream, one pair per step"}
 
+
+# ---- one rank ----------------------------------------------------------------------------------------------------------------
+def run_rank(args) -> None:
+    import torch
+    from layoutdit_amd import config as cfgs, dp, synth
+    from layoutdit_amd.modeling import DiTEncoder
+
+    if os.environ.get("LDIT_BENCH_DRYRUN") == "1":
+        # launcher / rendezvous rehearsal without a GPU (tests/test_dp_gloo.py): join over gloo, reduce, report
+        r = dp.init(backend="gloo")
+        dp.barrier(r)
+        worst = dp.max_over_ranks(r, float(r.rank + 1))
+        if r.is_main:
+            print(json.dumps({"dryrun": True, "n_gpus": r.world, "max_over_ranks": worst, "gpus_arg": args.gpus}), flush=True)
+        dp.finalize(r)
+        return
     r = dp.init()
     if r.world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={r.world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={r.world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: layoutdit_amd has no CPU path")
     dev = torch.device("cuda", r.local_rank)
@@ -114,74 +185,106 @@ def main() -> None:
 
     cfg = cfgs.GEOMETRIES[args.model]()
     weights = synth.synth_weights(cfg, seed=0)
-    model = DiTEncoder(cfg, compute_dtype=args.dtype).load_numpy(weights).to(dev).eval()
+    train = args.mode == "train"
+    model = DiTEncoder(cfg, compute_dtype=args.dtype).load_numpy(weights).to(dev)
     lo, hi = dp.shard_range(args.batch * r.world, r.rank, r.world)       # weak scaling: args.batch images per rank
     x_np = synth.synth_images(hi - lo, args.size, args.size, seed=1234, first_index=lo)
     x = torch.from_numpy(x_np).to(dev)                                    # resident in HBM before the timed region
-    if args.dtype == "fp8":
-        model.calibrate_fp8(x)                                            # per-tensor activation scales, untimed set-up
+    if train:
+        from layoutdit_amd.training import TrainStep
+        model.train()
+        stepper = TrainStep(model, r, lr=1e-4, weight_decay=0.0, seed=4321)   # trainer.py:62-68: AdamW(lr 1e-4, wd 0)
+        run = lambda: stepper.step(x)                                          # noqa: E731
+    else:
+        model.eval()
+        if args.dtype == "fp8":
+            model.calibrate_fp8(x)                                        # per-tensor activation scales, untimed set-up
+        run = lambda: model(x)                                            # noqa: E731
 
-    with torch.no_grad():
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    with torch.set_grad_enabled(False):
         for _ in range(max(args.warmup, 1)):
-            out = model(x)
+            out = run()
         torch.cuda.synchronize(dev)
         dp.barrier(r)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = model(x)
+        ev[0].record()
+        for i in range(args.steps):
+            out = run()
+            ev[i + 1].record()
         torch.cuda.synchronize(dev)
         dp.barrier(r)
         t1 = time.perf_counter()
     elapsed = dp.max_over_ranks(r, t1 - t0)
-    assert all(torch.isfinite(h).all() for h in out.hidden_states if h is not None)
+    step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    if train:
+        assert bool(torch.isfinite(stepper.flat_params).all())
+    else:
+        assert all(torch.isfinite(h).all() for h in out.hidden_states if h is not None)
 
     # second pass: per-kernel HIP events on the launch stream (same inputs, same K steps)
     timing: dict = {}
     if not args.no_roofline_pass:
         with torch.no_grad():
             for _ in range(args.steps):
-                model(x, _timing=timing)
+                if train:
+                    stepper.step(x, _timing=timing)
+                else:
+                    model(x, _timing=timing)
         torch.cuda.synchronize(dev)
 
     if r.is_main:
+        headline = (args.model, args.size, args.batch, args.dtype, args.mode) == ("base", 224, 64, "f32", "forward")
         images = args.batch * r.world * args.steps
         ms_per_step = 1e3 * elapsed / args.steps
+        what = "fwd" if not train else "train step (fwd+bwd+AdamW)"
         line = {
-            "metric": "images/sec ViT-B/16 224px bs=64 fwd"
-            if (args.model, args.size, args.batch, args.dtype) == ("base", 224, 64, "f32")
-            else f"images/sec ViT-{args.model}/16 {args.size}px bs={args.batch} {args.dtype} fwd",
+            "metric": "images/sec ViT-B/16 224px bs=64 fwd" if headline
+            else f"images/sec ViT-{args.model}/16 {args.size}px bs={args.batch} {args.dtype} {what}",
             "value": round(images / elapsed, 2), "unit": "images/sec", "n_gpus": r.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"ViT-{args.model}/16 {args.size}x{args.size} bs={args.batch} {args.dtype} forward, taps "
-                                   f"{cfg.taps}" + (" (BASELINE.json configs[1])"
-                                                    if (args.model, args.size, args.batch, args.dtype) == ("base", 224, 64, "f32")
-                                                    else ""),
+            "config": {"workload": f"ViT-{args.model}/16 {args.size}x{args.size} bs={args.batch} {args.dtype} "
+                                   f"{'forward' if not train else 'train step'}, taps {cfg.taps} "
+                                   f"(BASELINE.json configs[{args.config}])",
                        "images_per_gpu": args.batch, "global_batch": args.batch * r.world,
-                       "parallelism": f"dp{r.world}: batch-sharded replicas, no data-path collective",
+                       "parallelism": f"dp{r.world}: batch-sharded replicas, "
+                                      + ("bucketed gradient all-reduce (one bucket per layer) overlapped with backward"
+                                         if train else "no data-path collective"),
                        "weights": "synthetic seed 0", "images": "synthetic doc-like pages, seed 1234"},
+            "step_ms": percentiles(step_ms),
         }
-        flops_img = cfg.flops_per_image(args.size, args.size)
+        mult = 3 if train else 1                       # train step ~ 3x the forward's matmul FLOPs
+        flops_img = cfg.flops_per_image(args.size, args.size) * mult
         line["model_tflops"] = round(flops_img * args.batch * r.world / (ms_per_step * 1e-3) / 1e12, 2)
         peak = PEAK_TFLOPS[args.dtype]
         line["model_mfma_roofline_frac"] = round(line["model_tflops"] / (peak * r.world), 4)
-        if timing:
+        if timing and timing.get("gemm_launches"):
             n = int(timing["gemm_launches"])
-            gemm_flops = gemm_flops_per_image(cfg, args.size) * args.batch * args.steps
+            gemm_flops = gemm_flops_per_image(cfg, args.size) * mult * args.batch * args.steps
             achieved = gemm_flops / (timing["gemm_ms"] * 1e-3) / 1e12
+            traffic, source = pmc_traffic(args)
             line["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                                "traffic": pmc_traffic(args),
+                                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                                "traffic_source": source,
                                 "kernel": "fp32 MFMA GEMM family (patch-embed, qkv, o_proj, fc1, fc2)" if args.dtype == "f32"
-                                else f"{args.dtype} MFMA GEMM family (qkv, o_proj, fc1, fc2; patch-embed stays fp32)",
+                                else f"{args.dtype} MFMA GEMM family (qkv, o_proj, fc1, fc2"
+                                     + (" + their dgrad / wgrad" if train else "") + "; patch-embed stays fp32)",
                                 "launches": n, "avg_launch_ms": round(timing["gemm_ms"] / n, 5),
                                 "flops_per_launch": gemm_flops // n}
             line["kernel_ms_per_step"] = {k[:-3]: round(v / args.steps, 4) for k, v in timing.items() if k.endswith("_ms")}
-        if r.world == 1 and args.cpu_sample > 0 and args.model == "base" and args.dtype == "f32":
+        if r.world == 1 and args.cpu_sample > 0 and headline:
             line["cpu_baseline"] = cpu_baseline(cfg, weights, x_np, min(args.cpu_sample, args.batch))
         print(json.dumps(line), flush=True)
     dp.finalize(r)
+
+
+def main() -> None:
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_children(args.gpus))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -37,15 +37,16 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def init(backend: str | None = None) -> Rank:
+def init(backend: str | None = None, force_group: bool = False) -> Rank:
     """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (as ``torch.distributed.run`` sets them).
-    A single process (no WORLD_SIZE, or 1) needs no process group."""
+    A single process (no WORLD_SIZE, or 1) needs no process group; ``force_group`` creates one anyway (the 1-GPU box
+    rehearses the RCCL control plane that way, tests/test_gpu_dp.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -58,7 +59,7 @@ def init(backend: str | None = None) -> Rank:
 
 
 def barrier(r: Rank) -> None:
-    if r.world > 1:
+    if r.world > 1 or dist.is_initialized():
         if r.backend == "nccl":
             dist.barrier(device_ids=[r.local_rank])
         else:
@@ -66,7 +67,7 @@ def barrier(r: Rank) -> None:
 
 
 def max_over_ranks(r: Rank, value: float) -> float:
-    if r.world == 1:
+    if r.world == 1 and not dist.is_initialized():
         return float(value)
     dev = torch.device("cuda", r.local_rank) if r.backend == "nccl" else torch.device("cpu")
     t = torch.tensor([value], dtype=torch.float64, device=dev)
@@ -75,7 +76,7 @@ def max_over_ranks(r: Rank, value: float) -> float:
 
 
 def sum_over_ranks(r: Rank, value: float) -> float:
-    if r.world == 1:
+    if r.world == 1 and not dist.is_initialized():
         return float(value)
     dev = torch.device("cuda", r.local_rank) if r.backend == "nccl" else torch.device("cpu")
     t = torch.tensor([value], dtype=torch.float64, device=dev)
@@ -84,5 +85,5 @@ def sum_over_ranks(r: Rank, value: float) -> float:
 
 
 def finalize(r: Rank) -> None:
-    if r.world > 1 and dist.is_initialized():
+    if dist.is_initialized():
         dist.destroy_process_group()

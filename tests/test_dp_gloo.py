@@ -64,3 +64,27 @@ def test_two_ranks_over_gloo():
         assert abs(s - float(full[lo:hi].astype(np.float64).sum())) < 1e-9    # shard == rows of the global batch
         assert t == 2.0 and n == 6.0
         assert is_main == (rank == 0)
+
+
+def test_bench_launches_itself_at_n_greater_than_one():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's plain form): the parent must start
+    two ranks with the rendezvous in their environment and relay rank 0's single JSON line.  LDIT_BENCH_DRYRUN=1 keeps
+    the ranks on the CPU (gloo), everything up to the first GPU call is the real code path."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["LDIT_BENCH_DRYRUN"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec == {"dryrun": True, "n_gpus": 2, "max_over_ranks": 2.0, "gpus_arg": 2}
+    # and the torch.distributed.run form keeps working: WORLD_SIZE present -> no self-launch
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], env=env2, capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0 and json.loads(res.stdout.strip().splitlines()[-1])["n_gpus"] == 1

@@ -63,3 +63,26 @@ def test_two_gpu_ranks_reproduce_the_unsharded_batch_bit_for_bit():
     for t in cfg.taps:
         ref = full[t].cpu().numpy()
         np.testing.assert_array_equal(np.concatenate([g[4][t] for g in got]), ref)
+
+
+def test_rccl_control_plane_one_rank():
+    """The `nccl` (= RCCL) branch of dp.py - init with device_id, barrier(device_ids), all_reduce MAX / SUM, destroy - on
+    the box's one GPU with a one-rank group, in a child process (a process group is per process)."""
+    import subprocess
+    import sys
+    code = (
+        "import os, torch\n"
+        "from layoutdit_amd import dp\n"
+        "r = dp.init(backend='nccl', force_group=True)\n"
+        "assert r.backend == 'nccl' and torch.distributed.is_initialized()\n"
+        "dp.barrier(r)\n"
+        "assert dp.max_over_ranks(r, 3.5) == 3.5 and dp.sum_over_ranks(r, 2.0) == 2.0\n"
+        "g = torch.ones(1 << 20, device='cuda:0')\n"
+        "torch.distributed.all_reduce(g)\n"
+        "torch.cuda.synchronize(); assert float(g.sum()) == float(1 << 20)\n"
+        "dp.finalize(r); print('rccl-ok')\n")
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "rccl-ok" in res.stdout, res.stderr[-2000:]
