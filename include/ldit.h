@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LDIT_ABI_VERSION 1
+#define LDIT_ABI_VERSION 2
 #define LDIT_MAX_TAPS 8
 
 enum ldit_status {
@@ -60,7 +60,10 @@ enum ldit_fp8_act {
 enum ldit_epilogue {
     LDIT_EPI_BIAS = 0,       /* Y = X W^T + b                         nn.Linear; TF:305-307 (q,k,v), TF:349 */
     LDIT_EPI_BIAS_GELU = 1,  /* Y = gelu_erf(X W^T + b)               TF:353-354, TF:activations.py:70-89 */
-    LDIT_EPI_SCALE_RESID = 2 /* Y = R + lam (.) (X W^T + b)           TF:432-434 and TF:440-442 (LayerScale + residual) */
+    LDIT_EPI_SCALE_RESID = 2,/* Y = R + lam (.) (X W^T + b)           TF:432-434 and TF:440-442 (LayerScale + residual) */
+    /* train step, ldit_linear_bf16_ex only: */
+    LDIT_EPI_F32 = 4,        /* Y fp32 = X W^T (+ b)                  dgrad into LayerNorm backward; wgrad (split-K slabs) */
+    LDIT_EPI_GELU_BWD = 5    /* Y bf16 = (X W^T) (.) gelu'(aux)       dgrad of fc2 folded with the GELU derivative */
 };
 
 typedef void *ldit_stream;
@@ -223,6 +226,77 @@ int ldit_amax_f32(const void *src, int64_t n, void *out, ldit_stream stream);
  * are HOST arrays of B entries (device pointers / sizes); at most 65535 images per call. */
 int ldit_preprocess_f32(const void *const *images, const int32_t *heights, const int32_t *widths, int32_t B, int32_t in_ch,
                         float mean, float std, int32_t out_h, int32_t out_w, void *out, ldit_stream stream);
+
+/* ==== train step (BASELINE.json configs[2]: ViT-B/16 bs=64 bf16 forward + backward + AdamW) =============
+ * Replaces, for the encoder, what the reference's loop runs through torch.autograd and torch.optim:
+ *     loss_dict = self.model(images, targets) ; loss.backward() ; optimizer.step()     ref trainer.py:169-180
+ *     optimizer = AdamW(params, lr = 1e-4, weight_decay = 0)                           ref trainer.py:62-68
+ * bf16 build only (cfg.dtype = LDIT_BF16; BASELINE asks bf16 where the reference uses fp16 autocast + GradScaler).
+ *
+ * Parameters, gradients and the two AdamW moments are FLAT fp32 device blocks of ldit_flat_param_bytes(cfg) bytes, laid out
+ * like the fp32 packed block: patch_w, patch_b, cls, pos, then per layer ln1_w, ln1_b, wqkv [3C,C] = [Wq;Wk;Wv],
+ * bqkv [3C] = [bq;0;bv] (no key bias, TF:306: that third stays zero and receives a zero gradient), wo, bo, lam1, ln2_w,
+ * ln2_b, w1, b1, w2, b2, lam2.  ldit_flat_param_layout writes the 4 + 14 L + 1 float offsets in that order (last = total).
+ * Training requires the input grid to be the position table's own grid (no bicubic resampling in the backward). */
+size_t ldit_flat_param_bytes(const ldit_cfg *cfg);
+int ldit_flat_param_layout(const ldit_cfg *cfg, int64_t *offsets, int32_t n);
+
+/* bytes of: the activations kept between forward and backward / the backward's scratch / the transposed bf16 weights */
+size_t ldit_train_saved_bytes(const ldit_cfg *cfg, int32_t batch);
+size_t ldit_train_workspace_bytes(const ldit_cfg *cfg, int32_t batch);
+size_t ldit_train_wt_bytes(const ldit_cfg *cfg);
+
+/* flat fp32 parameters -> the bf16 packed block ldit_vit_forward[_train] streams from (as ldit_pack_weights would build it)
+ * + transposed bf16 copies of the four matrices per layer for the dgrad GEMMs.  Call after every optimizer step. */
+int ldit_pack_train(const ldit_cfg *cfg, const void *flat_params, void *packed, size_t packed_bytes, void *wT, size_t wt_bytes,
+                    ldit_stream stream);
+
+/* Training forward: as ldit_vit_forward, and keeps in `saved` what the backward needs (LayerNorm inputs and outputs, q|k|v,
+ * the attention output and its log-sum-exp, the pre-LayerScale branch outputs, the pre-GELU and post-GELU MLP hidden).
+ * drop_scales: device fp32 [layers][2][batch] or NULL - stochastic depth (TF:360-378,432-434,440-442): the factor the
+ * residual branch (0 = attention, 1 = MLP) of a layer is multiplied with for each sample, 0 or 1 / keep_prob; drawing
+ * them is the caller's job.  ms / launches: as ldit_vit_forward_timed (both NULL = plain enqueue, capturable). */
+int ldit_vit_forward_train(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batch, void *const *tap_out,
+                           const void *drop_scales, void *saved, size_t saved_bytes, ldit_stream stream, double *ms,
+                           int64_t *launches);
+
+/* Backward through stages stage_hi .. stage_lo (stage l >= 1 = encoder layer l, stage 0 = embeddings); a full backward is
+ * (layers, 0).  Splitting it into consecutive descending ranges lets the caller start the gradient all-reduce of finished
+ * layers while earlier ones are still being differentiated; the running gradient of the residual stream lives in
+ * `workspace` between calls.  dtaps[i] (device fp32 [batch, 1+P, C] or NULL) = gradient of the loss with respect to hidden
+ * state cfg->taps[i].  grads: flat fp32 block, OVERWRITTEN (not accumulated) for every parameter of the stages processed.
+ * drop_scales: the pointer given to the forward (NULL there = NULL here).  x: the forward's input (patch-embedding wgrad). */
+int ldit_vit_backward(const ldit_cfg *cfg, const void *packed, const void *wT, const void *x, int32_t batch, void *const *dtaps,
+                      const void *drop_scales, const void *saved, size_t saved_bytes, void *grads, size_t grads_bytes,
+                      void *workspace, size_t workspace_bytes, int32_t stage_hi, int32_t stage_lo, ldit_stream stream,
+                      double *ms, int64_t *launches);
+
+/* Fused AdamW over n fp32 elements (torch.optim.AdamW semantics, decoupled weight decay), step counts from 1:
+ *   g = grads * grad_scale ; p *= 1 - lr wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+ *   p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps).   n % 4 == 0, all pointers 16-byte aligned. */
+int ldit_adamw_step(void *params, const void *grads, void *exp_avg, void *exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int32_t step, float grad_scale, ldit_stream stream);
+
+/* ---- the kernels of the backward, one entry point each (unit parity tests) ---- */
+/* ldit_attention_bf16 that also writes lse[b][h][q] = log2 sum_k exp2(scale log2(e) q.k)  (fp32 [B, H, N]) */
+int ldit_attention_fwd_lse_bf16(const void *Q, const void *K, const void *V, void *O, void *lse, int64_t B, int64_t N, int64_t H,
+                                int64_t D, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, ldit_stream stream);
+/* dQ, dK, dV (bf16, row stride lddqkv) from Q, K, V (row stride ldqkv), O, dO and the forward's lse.  D == 64, N <= 256. */
+int ldit_attention_bwd_bf16(const void *Q, const void *K, const void *V, const void *O, const void *dO, const void *lse, void *dQ,
+                            void *dK, void *dV, int64_t B, int64_t N, int64_t H, int64_t D, int64_t ldqkv, int64_t ldo, int64_t lddo,
+                            int64_t lddqkv, float scale, ldit_stream stream);
+/* LayerNorm backward: dh += d/dx ; dgamma = sum_rows dy xhat ; dbeta = sum_rows dy.  scratch: ldit_layernorm_bwd_scratch_bytes. */
+size_t ldit_layernorm_bwd_scratch_bytes(int64_t rows, int64_t C);
+int ldit_layernorm_bwd_f32(const void *dy, const void *x, const void *gamma, void *dh, int64_t rows, int64_t C, float eps,
+                           void *dgamma, void *dbeta, void *scratch, size_t scratch_bytes, ldit_stream stream);
+/* ldit_linear_bf16 with the train step's extras: Ypre (bf16 [M,N], stride ldy) receives X W^T + b before GELU / LayerScale;
+ * rowscale (fp32 [M]) multiplies lam per row; aux (bf16 [M,N], stride ldaux) is the pre-activation of LDIT_EPI_GELU_BWD;
+ * splits > 1 (LDIT_EPI_F32 only): K is cut into `splits` ranges, range s writes its own fp32 slab Y + s M ldy, to be summed
+ * with ldit_reduce_slabs_f32. */
+int ldit_linear_bf16_ex(const void *X, int64_t lda, const void *W, const void *bias, void *Y, int64_t ldy, int64_t M, int64_t N,
+                        int64_t K, int32_t epilogue, const void *lam, const void *R, void *Y2, void *Ypre, const void *rowscale,
+                        const void *aux, int64_t ldaux, int32_t splits, ldit_stream stream);
+int ldit_reduce_slabs_f32(const void *slabs, void *out, int64_t n, int32_t count, ldit_stream stream);
 
 #ifdef __cplusplus
 }

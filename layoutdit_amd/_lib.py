@@ -11,12 +11,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libldit_hip.so")
 
-LDIT_ABI_VERSION = 1
+LDIT_ABI_VERSION = 2
 LDIT_MAX_TAPS = 8
 DTYPE_F32, DTYPE_BF16, DTYPE_FP8 = 0, 1, 3
 FP8_A_COUNT = 4
 LDIT_OK, LDIT_EINVAL, LDIT_EWORKSPACE, LDIT_EHIP, LDIT_EUNSUPPORTED = 0, -1, -2, -3, -4
-EPI_BIAS, EPI_BIAS_GELU, EPI_SCALE_RESID = 0, 1, 2
+EPI_BIAS, EPI_BIAS_GELU, EPI_SCALE_RESID, EPI_F32, EPI_GELU_BWD = 0, 1, 2, 4, 5
 K_GEMM, K_ATTENTION, K_LAYERNORM, K_OTHER, K_COUNT = 0, 1, 2, 3, 4
 KERNEL_FAMILIES = ("gemm", "attention", "layernorm", "other")
 
@@ -67,6 +67,26 @@ SIGNATURES = {
     "ldit_amax_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "ldit_preprocess_f32": (C.c_int, [C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i32), _i32, _i32, _f32, _f32, _i32, _i32,
                                       _vp, _vp]),
+    # train step
+    "ldit_flat_param_bytes": (_sz, [C.POINTER(LditCfg)]),
+    "ldit_flat_param_layout": (C.c_int, [C.POINTER(LditCfg), C.POINTER(_i64), _i32]),
+    "ldit_train_saved_bytes": (_sz, [C.POINTER(LditCfg), _i32]),
+    "ldit_train_workspace_bytes": (_sz, [C.POINTER(LditCfg), _i32]),
+    "ldit_train_wt_bytes": (_sz, [C.POINTER(LditCfg)]),
+    "ldit_pack_train": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _sz, _vp, _sz, _vp]),
+    "ldit_vit_forward_train": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _i32, C.POINTER(_vp), _vp, _vp, _sz, _vp,
+                                         C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ldit_vit_backward": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _vp, _i32, C.POINTER(_vp), _vp, _vp, _sz, _vp, _sz, _vp, _sz,
+                                    _i32, _i32, _vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ldit_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+    "ldit_attention_fwd_lse_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp]),
+    "ldit_attention_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                          _i64, _f32, _vp]),
+    "ldit_layernorm_bwd_scratch_bytes": (_sz, [_i64, _i64]),
+    "ldit_layernorm_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp, _vp, _sz, _vp]),
+    "ldit_linear_bf16_ex": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                      _i32, _vp]),
+    "ldit_reduce_slabs_f32": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
 }
 
 _lib = None

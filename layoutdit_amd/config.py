@@ -23,6 +23,7 @@ class DiTConfig:
     num_channels: int = 3
     layer_norm_eps: float = 1e-12  # configuration_beit.py:81
     layer_scale_init_value: float = 0.1
+    drop_path_rate: float = 0.1    # stochastic depth in train mode, layer i drops with rate * i / (L-1) (configuration_beit.py:90)
     output_hidden_states: bool = True
     # which hidden states the caller consumes; None -> DiTBackbone's [d/3, d/2, 2d/3, d]
     taps: List[int] = field(default_factory=list)

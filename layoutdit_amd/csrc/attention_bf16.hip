@@ -54,7 +54,8 @@ template <int KT, int NW, bool OUT_FP8>
 __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const bf16_t *__restrict__ Q, const bf16_t *__restrict__ K,
                                                              const bf16_t *__restrict__ V, void *__restrict__ Ov,
                                                              int N, int H, int ldq, int ldk, int ldv, int ldo,
-                                                             float scale, int nqg, const float *__restrict__ qscale)
+                                                             float scale, int nqg, const float *__restrict__ qscale,
+                                                             float *__restrict__ lse)
 {
     constexpr int KC = KT * 32, HALF = KC * KROWB, STAGE = 2 * HALF;     // keys per chunk; K image, then V image
     constexpr int PIECES = KC / 8, PPW = PIECES / NW;                    // 1-KB DMA pieces (8 keys) per operand, per wave
@@ -251,6 +252,9 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
     const float l = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = OUT_FP8 ? 1.0f / (l * qscale[0]) : 1.0f / l;
     const int qrow = qt * 32 + c32;
+    // train step: log2-domain log-sum-exp of the scaled scores, L2 = log2 sum_k exp2(c s_k) = m c + log2 l, so that the
+    // backward recomputes p = exp2(c s - L2) with no row maximum (layout [B, H, N])
+    if (lse && h == 0 && qrow < N) lse[((size_t)b * H + head) * N + qrow] = __builtin_fmaf(m_run, c, __builtin_amdgcn_logf(l));
     if (OUT_FP8) {
         if (qrow < N) {
             unsigned char *op = static_cast<unsigned char *>(Ov) + (tok0 + qrow) * ldo + head * 64 + 4 * h;
@@ -278,7 +282,7 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
 
 template <bool OUT_FP8>
 static int launch_attn(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ldq, int ldk, int ldv,
-                       int ldo, float scale, const float *qscale, hipStream_t stream)
+                       int ldo, float scale, const float *qscale, float *lse, hipStream_t stream)
 {
     if (B <= 0 || N <= 0 || H <= 0) return fail(LDIT_EINVAL, "attention_bf16: empty problem");
     if (D != 64) return fail(LDIT_EUNSUPPORTED, "attention_bf16: head_dim=%d, only 64 is implemented", D);
@@ -296,7 +300,7 @@ static int launch_attn(const void *Q, const void *K, const void *V, void *O, int
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)(B * H * nqg)), dim3(NW * 64), lds, stream, static_cast<const bf16_t *>(Q),
                            static_cast<const bf16_t *>(K), static_cast<const bf16_t *>(V), O, N, H, ldq, ldk, ldv, ldo, scale, nqg,
-                           qscale);
+                           qscale, lse);
         return LDIT_OK;
     };
     // LDS = two stages of (K image + V image).  64-key chunks: 32 KB and 128 VGPRs -> four workgroups per CU (four waves per
@@ -311,14 +315,22 @@ static int launch_attn(const void *Q, const void *K, const void *V, void *O, int
 int launch_attention_bf16(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ldq, int ldk,
                           int ldv, int ldo, float scale, hipStream_t stream)
 {
-    return launch_attn<false>(Q, K, V, O, B, N, H, D, ldq, ldk, ldv, ldo, scale, nullptr, stream);
+    return launch_attn<false>(Q, K, V, O, B, N, H, D, ldq, ldk, ldv, ldo, scale, nullptr, nullptr, stream);
+}
+
+// train step: also writes the log2-domain log-sum-exp per (image, head, query) for attention_bwd_bf16
+int launch_attention_bf16_lse(const void *Q, const void *K, const void *V, void *O, float *lse, int B, int N, int H, int D, int ldq,
+                              int ldk, int ldv, int ldo, float scale, hipStream_t stream)
+{
+    if (!lse) return fail(LDIT_EINVAL, "attention_bf16: lse is null");
+    return launch_attn<false>(Q, K, V, O, B, N, H, D, ldq, ldk, ldv, ldo, scale, nullptr, lse, stream);
 }
 
 int launch_attention_bf16_fp8out(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ldq,
                                  int ldk, int ldv, int ldo, float scale, const float *qscale, hipStream_t stream)
 {
     if (!qscale) return fail(LDIT_EINVAL, "attention_bf16: fp8 output needs a scale");
-    return launch_attn<true>(Q, K, V, O, B, N, H, D, ldq, ldk, ldv, ldo, scale, qscale, stream);
+    return launch_attn<true>(Q, K, V, O, B, N, H, D, ldq, ldk, ldv, ldo, scale, qscale, nullptr, stream);
 }
 
 }  // namespace ldit

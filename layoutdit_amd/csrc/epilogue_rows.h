@@ -27,10 +27,12 @@ enum { EPI_OUT_BF16 = 0, EPI_OUT_FP8 = 1, EPI_OUT_F32 = 2 };
 // activation x weight scale when wscale is null; 1 for bf16).  The arithmetic is spelled with explicit fmas, identically
 // to the direct stores of the ragged tiles, so that a row gets the same bits whichever path its tile takes (batch
 // invariance of the bf16 / fp8 builds).
+// `x` (train step only): bf16 copy of t before GELU / LayerScale (Ypre), per-row factor on lam (rowscale), pre-activation of
+// the GELU derivative (aux).
 template <int TM, int TN, int EPI, int OUT>
 __device__ __forceinline__ void store_rows_via_lds(const f32x16 (&acc)[TM][TN], char *buf, void *Yv, float *Y2, const float *R,
                                                    const float *bias, const float *lam, const float *wscale, int ldy, int mw,
-                                                   int nw, int lane, float ab, float oinv)
+                                                   int nw, int lane, float ab, float oinv, const GemmExtra x = GemmExtra{})
 {
     static_assert(TN % 2 == 0, "slabs are 64 columns wide");
     const int c32 = lane & 31, h = lane >> 5;
@@ -63,16 +65,32 @@ __device__ __forceinline__ void store_rows_via_lds(const f32x16 (&acc)[TM][TN], 
                 f32x4 v = *reinterpret_cast<const f32x4 *>(buf + row * EPI_ROW_BYTES + rq * 16);
                 const unsigned o = (unsigned)(mw + 32 * i + row) * (unsigned)ldy + n;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = __builtin_fmaf(v[e], abq[e], biasq[e]);
-                    if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
-                    v[e] = t;
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], abq[e], biasq[e]);
+                if ((EPI == EPI_BIAS_GELU || EPI == EPI_SCALE_RESID) && x.Ypre) {
+                    const epi_bf16x4 pre = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *reinterpret_cast<epi_bf16x4 *>(static_cast<__bf16 *>(x.Ypre) + o) = pre;
+                }
+                if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_lp(v[e]);
+                }
+                if (EPI == EPI_GELU_BWD) {
+                    const epi_bf16x4 a = *reinterpret_cast<const epi_bf16x4 *>(
+                        static_cast<const __bf16 *>(x.aux) + ((unsigned)(mw + 32 * i + row) * (unsigned)x.ldaux + n));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_lp((float)a[e]);
                 }
                 if (OUT == EPI_OUT_F32) {
                     if (EPI == EPI_SCALE_RESID) {
                         const f32x4 res = *reinterpret_cast<const f32x4 *>(R + o);
+                        if (x.rowscale) {
+                            const float rs = x.rowscale[mw + 32 * i + row];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(lamq[e], v[e], res[e]);
+                            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(lamq[e] * rs, v[e], res[e]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(lamq[e], v[e], res[e]);
+                        }
                     }
                     *reinterpret_cast<f32x4 *>(static_cast<float *>(Yv) + o) = v;
                     if (Y2) *reinterpret_cast<f32x4 *>(Y2 + o) = v;

@@ -52,7 +52,10 @@ struct GemmArgsH {
     const float *R;      // [M, N] fp32, may alias Y
     int M, N, K, lda, ldy;
     int direct_epi;      // LDIT_GEMM_DIRECT_EPILOGUE=1: interior tiles stored straight from the accumulators (A/B experiments)
+    GemmExtra x;         // train-step operands (Ypre, rowscale, aux, split-K); defaults = inference
 };
+
+template <int EPI> constexpr bool f32_out() { return EPI == EPI_SCALE_RESID || EPI == EPI_F32; }
 
 // MODE 0: tile inside the matrix, 16-B / 8-B accesses unchecked; MODE 1: columns inside, rows past M skipped (the ragged
 // last row tile keeps its vector accesses - a lane owns a row, so the element-wise path does not coalesce and cost ~20 us);
@@ -91,19 +94,38 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
                 }
                 asm volatile("" ::: "memory");
             }
+            const float rs = (EPI == EPI_SCALE_RESID && p.x.rowscale) ? p.x.rowscale[m] : 1.0f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = nw + j * 32 + 8 * g + 4 * h;
                 const unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
                 f32x4 v;
 #pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bias[g][e];
+                if ((EPI == EPI_BIAS_GELU || EPI == EPI_SCALE_RESID) && p.x.Ypre) {
+                    bf16_t *yp = static_cast<bf16_t *>(p.x.Ypre);
+                    if (MODE != 2) {
+                        const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        *reinterpret_cast<bf16x4 *>(yp + o) = pk;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) yp[o + e] = (bf16_t)v[e];
+                    }
+                }
+                if (EPI == EPI_GELU_BWD) {
+                    const bf16_t *ax = static_cast<const bf16_t *>(p.x.aux) + ((unsigned)m * (unsigned)p.x.ldaux + (unsigned)n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= (MODE != 2 || n + e < p.N) ? gelu_grad_lp((float)ax[e]) : 0.0f;
+                }
+#pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = acc[i][j][4 * g + e] + bias[g][e];
+                    float t = v[e];
                     if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
-                    if (EPI == EPI_SCALE_RESID) t = __builtin_fmaf(lam[g][e], t, res[g][e]);
+                    if (EPI == EPI_SCALE_RESID) t = p.x.rowscale ? __builtin_fmaf(lam[g][e] * rs, t, res[g][e]) : __builtin_fmaf(lam[g][e], t, res[g][e]);
                     v[e] = t;
                 }
-                if (EPI == EPI_SCALE_RESID) {
+                if (f32_out<EPI>()) {
                     float *y = static_cast<float *>(p.Y);
                     if (MODE != 2) {
                         *reinterpret_cast<f32x4 *>(y + o) = v;
@@ -133,8 +155,9 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
 // WM x WN waves per workgroup, each owning TM x TN 32x32 tiles.  2 x 4 waves (512 threads, two waves per SIMD) let one
 // wave's MFMAs cover the other's LDS reads, DMA issue and barrier waits.
 template <int WM, int WN, int TM, int TN, int EPI>
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(const GemmArgsH p)
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(const GemmArgsH p0)
 {
+    GemmArgsH p = p0;
     constexpr int NWAVES = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, ROWS = BM + BN, NLD = ROWS / (8 * NWAVES);
     static_assert(ROWS % (8 * NWAVES) == 0 && BM % 8 == 0, "DMA pieces must split evenly over the waves");
@@ -146,11 +169,22 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     const int c32 = lane & 31, h = lane >> 5;
 
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
-    const int ntiles = nbm * nbn;
+    const int ntiles = nbm * nbn, nblocks = ntiles * p.x.splits;
     int tile;
     {
-        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = ntiles >> 3, rr = ntiles & 7;
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = nblocks >> 3, rr = nblocks & 7;
         tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    int nk = p.K / BKB;
+    if (EPI == EPI_F32 && p.x.splits > 1) {
+        // split-K (wgrad: K = tokens of the batch, output tiles few): this block multiplies k-tiles [kt0, kt0 + nk) into its
+        // own fp32 slab; ldit's reduce kernel adds the slabs in a fixed order
+        const int split = tile / ntiles, per = (nk + p.x.splits - 1) / p.x.splits, kt0 = split * per;
+        tile -= split * ntiles;
+        nk = nk - kt0 < per ? nk - kt0 : per;
+        p.A += kt0 * BKB;
+        p.W += kt0 * BKB;
+        p.Y = static_cast<float *>(p.Y) + (size_t)split * (size_t)p.M * (size_t)p.ldy;
     }
     const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
 
@@ -188,7 +222,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int sw = (c32 >> 1) & 7;
-    const int nk = p.K / BKB;
     const int a_row = (wm * TM * 32 + c32) * ROWB, b_row = (BM + wn * TN * 32 + c32) * ROWB;
     auto load_frags = [&](int stage, int s, bf16x8(&xa)[TM], bf16x8(&wb)[TN]) {
         const char *base = smem + stage * (ROWS * ROWB) + ((s * 2 + h) ^ sw) * 16;
@@ -319,8 +352,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
     if (cols_in && m0 + BM <= p.M && !p.direct_epi) {
         __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
-        store_rows_via_lds<TM, TN, EPI, EPI == EPI_SCALE_RESID ? EPI_OUT_F32 : EPI_OUT_BF16>(
-            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, nullptr, p.ldy, mw, nw, lane, 1.0f, 1.0f);
+        store_rows_via_lds<TM, TN, EPI, f32_out<EPI>() ? EPI_OUT_F32 : EPI_OUT_BF16>(
+            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, nullptr, p.ldy, mw, nw, lane, 1.0f, 1.0f, p.x);
     } else if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
     else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
     else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
@@ -346,7 +379,7 @@ int launch_h(const GemmArgsH &a, hipStream_t stream)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(tiles * a.x.splits), dim3(64 * WM * WN), lds, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }
@@ -439,11 +472,15 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_skinny(const GemmArgsH p)
         if (n >= p.N) break;
         float t = (e < 4 ? s0[e] : s1[e - 4]) + (p.bias ? p.bias[n] : 0.0f);
         const size_t o = (size_t)row * p.ldy + n;
+        if ((EPI == EPI_BIAS_GELU || EPI == EPI_SCALE_RESID) && p.x.Ypre) static_cast<bf16_t *>(p.x.Ypre)[o] = (bf16_t)t;
         if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
+        if (EPI == EPI_GELU_BWD) t *= gelu_grad_lp((float)static_cast<const bf16_t *>(p.x.aux)[(size_t)row * p.x.ldaux + n]);
         if (EPI == EPI_SCALE_RESID) {
-            t = __builtin_fmaf(p.lam[n], t, p.R[o]);
+            t = p.x.rowscale ? __builtin_fmaf(p.lam[n] * p.x.rowscale[row], t, p.R[o]) : __builtin_fmaf(p.lam[n], t, p.R[o]);
             static_cast<float *>(p.Y)[o] = t;
             if (p.Y2) p.Y2[o] = t;
+        } else if (EPI == EPI_F32) {
+            static_cast<float *>(p.Y)[o] = t;
         } else {
             static_cast<bf16_t *>(p.Y)[o] = (bf16_t)t;
         }
@@ -469,7 +506,7 @@ int launch_skinny(const GemmArgsH &a, hipStream_t stream)
 template <int EPI>
 int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
 {
-    if (a.M <= 64 && a.K % 128 == 0 && !getenv("LDIT_GEMM_BF16_TILE")) return launch_skinny<EPI>(a, stream);
+    if (a.M <= 64 && a.K % 128 == 0 && a.x.splits == 1 && !getenv("LDIT_GEMM_BF16_TILE")) return launch_skinny<EPI>(a, stream);
     // Time model fitted to scripts/gemm_bf16_bench.py on ViT-B / ViT-L shapes, M = 3 k .. 25 k (profiles/README.md), in us:
     //   256 x 256, 8 waves (one workgroup per CU):  strict rounds of 256 tiles, each  a[epi] + 19.5e-3 K
     //   128 x 128 (two per CU, they overlap each other's prologue / epilogue):  rounds of 256 tiles, each  r[epi] + 7.6e-3 K,
@@ -477,11 +514,14 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
     // Measured and dropped (profiles/README.md): a four-stage and a five-stage counted-vmcnt ring, a 256 x 128 ring at two
     // workgroups per CU, a barrier-phased ping-pong of the two waves per SIMD, a v_mfma_f32_16x16x32_bf16 build and a
     // four-wave 256 x 256 tile - none beat this kernel on any shape; the 256 x 128 tile stays selectable for experiments.
-    const double a256[3] = {19.0, 18.5, 25.0}, r128[3] = {5.2, 5.0, 7.7};
-    const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    const double c256 = (double)((t256 + 255) / 256) * (a256[EPI] + 19.5e-3 * a.K);
-    double c128 = (double)((t128 + 255) / 256) * (r128[EPI] + 7.6e-3 * a.K);
-    if (c128 < 5.0 + 11.4e-3 * a.K) c128 = 5.0 + 11.4e-3 * a.K;
+    // (EPI_EMBED unused here; EPI_F32 priced like the residual epilogue, EPI_GELU_BWD like the GELU one)
+    const double a256[6] = {19.0, 18.5, 25.0, 0.0, 25.0, 18.5}, r128[6] = {5.2, 5.0, 7.7, 0.0, 7.7, 5.0};
+    const long sp = a.x.splits;
+    const long t256 = sp * ((a.M + 255) / 256) * ((a.N + 255) / 256), t128 = sp * ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const double Ks = (double)a.K / (double)sp;            // k-depth one block walks
+    const double c256 = (double)((t256 + 255) / 256) * (a256[EPI] + 19.5e-3 * Ks);
+    double c128 = (double)((t128 + 255) / 256) * (r128[EPI] + 7.6e-3 * Ks);
+    if (c128 < 5.0 + 11.4e-3 * Ks) c128 = 5.0 + 11.4e-3 * Ks;
     int pick = c256 <= c128 ? 3 : 2;
     if (const char *force = getenv("LDIT_GEMM_BF16_TILE")) {
         if (force[0] >= '1' && force[0] <= '3' && force[1] == 0) pick = force[0] - '0';
@@ -509,39 +549,55 @@ __global__ void __launch_bounds__(256) cvt_f32_bf16(const float *__restrict__ sr
 }  // namespace
 
 static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K,
-                                int epi, const float *lam, const float *R, float *Y2, hipStream_t stream);
+                                int epi, const float *lam, const float *R, float *Y2, const GemmExtra &x, hipStream_t stream);
 
 // A few rows past a multiple of the 256-row tile (M = 16 x 1025 = 64 x 256 + 16) would cost a whole extra row of
 // workgroups - a full extra round of the machine for N = 1024.  Such a ragged tail is peeled off into a second, tiny
-// launch on the 128 x 128 tiling; the main part then fills 256 CUs in whole rounds.
-int launch_gemm_bf16(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
-                     const float *lam, const float *R, float *Y2, hipStream_t stream)
+// launch (split-K skinny kernel); the main part then fills 256 CUs in whole rounds.  The peeled rows are summed in a
+// different k-order than tile rows: the LAST image of such a batch is bit-reproducible only for the same batch layout.
+int launch_gemm_bf16_ex(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
+                        const float *lam, const float *R, float *Y2, const GemmExtra &x, hipStream_t stream)
 {
     const int rem = M % 256;
     const long nbn = (N + 255) / 256, full = ((long)M / 256 + 1) * nbn, mainp = ((long)M / 256) * nbn;
-    if (rem != 0 && rem <= 64 && M > 256 && (full + 255) / 256 > (mainp + 255) / 256) {   // peel only when it saves a round
+    if (rem != 0 && rem <= 64 && M > 256 && x.splits == 1 && (full + 255) / 256 > (mainp + 255) / 256) {   // peel only when it saves a round
         const int main_rows = M - rem;
-        const size_t out_elt = epi == EPI_SCALE_RESID ? 4 : 2;
-        int rc = launch_gemm_bf16_one(A, lda, W, bias, Y, ldy, main_rows, N, K, epi, lam, R, Y2, stream);
+        const size_t out_elt = (epi == EPI_SCALE_RESID || epi == EPI_F32) ? 4 : 2;
+        int rc = launch_gemm_bf16_one(A, lda, W, bias, Y, ldy, main_rows, N, K, epi, lam, R, Y2, x, stream);
         if (rc != LDIT_OK) return rc;
         const char *At = static_cast<const char *>(A) + (size_t)main_rows * lda * 2;
         char *Yt = static_cast<char *>(Y) + (size_t)main_rows * ldy * out_elt;
+        GemmExtra xt = x;
+        if (x.Ypre) xt.Ypre = static_cast<char *>(x.Ypre) + (size_t)main_rows * ldy * 2;
+        if (x.rowscale) xt.rowscale = x.rowscale + main_rows;
+        if (x.aux) xt.aux = static_cast<const char *>(x.aux) + (size_t)main_rows * x.ldaux * 2;
         return launch_gemm_bf16_one(At, lda, W, bias, Yt, ldy, rem, N, K, epi, lam, R ? R + (size_t)main_rows * ldy : nullptr,
-                                    Y2 ? Y2 + (size_t)main_rows * ldy : nullptr, stream);
+                                    Y2 ? Y2 + (size_t)main_rows * ldy : nullptr, xt, stream);
     }
-    return launch_gemm_bf16_one(A, lda, W, bias, Y, ldy, M, N, K, epi, lam, R, Y2, stream);
+    return launch_gemm_bf16_one(A, lda, W, bias, Y, ldy, M, N, K, epi, lam, R, Y2, x, stream);
+}
+
+int launch_gemm_bf16(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
+                     const float *lam, const float *R, float *Y2, hipStream_t stream)
+{
+    return launch_gemm_bf16_ex(A, lda, W, bias, Y, ldy, M, N, K, epi, lam, R, Y2, GemmExtra{}, stream);
 }
 
 static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K,
-                                int epi, const float *lam, const float *R, float *Y2, hipStream_t stream)
+                                int epi, const float *lam, const float *R, float *Y2, const GemmExtra &x, hipStream_t stream)
 {
     if (M <= 0 || N <= 0 || K <= 0) return fail(LDIT_EINVAL, "gemm_bf16: empty problem");
     if (K % BKB) return fail(LDIT_EUNSUPPORTED, "gemm_bf16: K=%d must be a multiple of %d", K, BKB);
     if (!A || !W || !Y) return fail(LDIT_EINVAL, "gemm_bf16: null operand");
     if (!aligned16(A) || !aligned16(W) || (lda & 7)) return fail(LDIT_EINVAL, "gemm_bf16: operands must be 16-byte aligned");
+    if (x.splits < 1 || x.splits > K / BKB || (x.splits > 1 && epi != EPI_F32))
+        return fail(LDIT_EINVAL, "gemm_bf16: %d K-splits need the fp32 slab epilogue and at least one k-tile each", x.splits);
+    if (x.splits > 1 && ((K / BKB + x.splits - 1) / x.splits) * (x.splits - 1) >= K / BKB)
+        return fail(LDIT_EINVAL, "gemm_bf16: %d K-splits leave an empty slab for K=%d", x.splits, K);
+    if (x.Ypre && (reinterpret_cast<uintptr_t>(x.Ypre) & 7u)) return fail(LDIT_EINVAL, "gemm_bf16: Ypre misaligned");
     GemmArgsH a{};
     a.A = static_cast<const bf16_t *>(A); a.W = static_cast<const bf16_t *>(W); a.Y = Y; a.Y2 = Y2; a.bias = bias; a.lam = lam;
-    a.R = R; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldy = ldy;
+    a.R = R; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldy = ldy; a.x = x;
     static const int direct = [] { const char *e = getenv("LDIT_GEMM_DIRECT_EPILOGUE"); return (e && *e == '1') ? 1 : 0; }();
     a.direct_epi = direct;
     switch (epi) {
@@ -550,6 +606,10 @@ static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const flo
         case EPI_SCALE_RESID:
             if (!lam || !R) return fail(LDIT_EINVAL, "gemm_bf16: scale+residual epilogue needs lam and R");
             return launch_h_tiled<EPI_SCALE_RESID>(a, stream);
+        case EPI_F32: return launch_h_tiled<EPI_F32>(a, stream);
+        case EPI_GELU_BWD:
+            if (!x.aux || (x.ldaux & 3) || (reinterpret_cast<uintptr_t>(x.aux) & 7u)) return fail(LDIT_EINVAL, "gemm_bf16: GELU-backward epilogue needs an aligned pre-activation operand");
+            return launch_h_tiled<EPI_GELU_BWD>(a, stream);
         default: return fail(LDIT_EINVAL, "gemm_bf16: unknown epilogue %d", epi);
     }
 }

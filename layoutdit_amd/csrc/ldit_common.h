@@ -68,6 +68,19 @@ __device__ __forceinline__ float gelu_erf_lp(float v)
     return __builtin_fmaf(hv, er, hv);
 }
 
+// d/dv of the erf-GELU, same A-S 7.1.25 erf as gelu_erf_lp: Phi(v) + v phi(v) with Phi = (1 + erf(v / sqrt 2)) / 2,
+// phi = exp(-v^2 / 2) / sqrt(2 pi).  Used by the bf16 backward (the product is rounded to bf16 right after).
+__device__ __forceinline__ float gelu_grad_lp(float v)
+{
+    const float x = __builtin_fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.47047f, x, 1.0f));
+    const float poly = t * __builtin_fmaf(t, __builtin_fmaf(t, 0.7478556f, -0.0958798f), 0.3480242f);
+    const float e = __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);      // exp(-v^2 / 2)
+    const float er = __builtin_copysignf(__builtin_fmaf(-poly, e, 1.0f), v);
+    const float cdf = __builtin_fmaf(0.5f, er, 0.5f);
+    return __builtin_fmaf(v * 0.39894228040143267794f, e, cdf);
+}
+
 // 4 floats -> 4 fp8 e4m3 (round to nearest even, saturating at +-448), packed little-endian in one dword
 __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d)
 {
@@ -82,7 +95,18 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 
 // ---- GEMM ----------------------------------------------------------------------------------------------------
 enum AMode { A_ROWMAJOR = 0, A_PATCH = 1 };
-enum Epi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_SCALE_RESID = 2, EPI_EMBED = 3 };
+enum Epi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_SCALE_RESID = 2, EPI_EMBED = 3,
+           EPI_F32 = 4,        // bf16 GEMM only: Y fp32 = acc (+ bias); dgrad into LayerNorm backward, wgrad slabs
+           EPI_GELU_BWD = 5 }; // bf16 GEMM only: Y bf16 = acc * gelu'(aux)   (dgrad of fc2 folded with the GELU derivative)
+
+// Optional operands of the bf16 GEMM used by the train step (training.hip); all null / 1 for inference.
+struct GemmExtra {
+    void *Ypre = nullptr;              // bf16 [M,N], row stride ldy: acc + bias BEFORE GELU / LayerScale (saved for backward)
+    const float *rowscale = nullptr;   // fp32 [M]: per-row factor on lam (stochastic depth, TF:360-378), EPI_SCALE_RESID
+    const void *aux = nullptr;         // bf16 [M,N], row stride ldaux: pre-activation for EPI_GELU_BWD
+    int ldaux = 0;
+    int splits = 1;                    // EPI_F32: K split into `splits` slabs, slab s at (float*)Y + s * M * ldy
+};
 
 struct GemmArgs {
     const float *A;      // [M, K] row-major (A_ROWMAJOR) or the NCHW image batch (A_PATCH)
@@ -120,6 +144,8 @@ int launch_preprocess(const float *const *images, const int *heights, const int 
                       float std, int out_h, int out_w, float *out, hipStream_t stream);
 int launch_gemm_bf16(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
                      const float *lam, const float *R, float *Y2, hipStream_t stream);
+int launch_gemm_bf16_ex(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
+                        const float *lam, const float *R, float *Y2, const GemmExtra &x, hipStream_t stream);
 int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream);
 // fp8: the per-tensor part of the accumulator's dequantisation is d_act[0] when d_act is non-null (device), else the host
 // value ab_scale; d_wrow (device, [N], optional) multiplies per-output-channel weight scales onto it; d_out (device, 1
@@ -136,5 +162,41 @@ int launch_layernorm_fp8out(const float *X, const float *g, const float *b, void
 int launch_attention_bf16_fp8out(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ldq,
                                  int ldk, int ldv, int ldo, float scale, const float *qscale, hipStream_t stream);
 int launch_pack_qkv_bias(const float *bq, const float *bv, float *dst, int C, hipStream_t stream);
+
+// ---- train step (train_ops.hip, attention_bwd_bf16.hip, api_train.hip) ----------------------------------------------------
+// second stage of the column reductions / split-K slab sums: out[j][n] = sum_{p < P[j]} part[j][p * stride[j] + n]
+struct ReduceJobs {
+    int n = 0;
+    int first_block[16];
+    const float *part[16];
+    float *out[16];
+    int64_t N[16];
+    int P[16];
+    int64_t stride[16];
+    bool full() const { return n == 16; }
+    void add(const float *part_, float *out_, int64_t N_, int P_, int64_t stride_)
+    {
+        part[n] = part_; out[n] = out_; N[n] = N_; P[n] = P_; stride[n] = stride_; ++n;
+    }
+};
+int launch_reduce_jobs(ReduceJobs &jobs, hipStream_t stream);     // resets jobs.n
+int launch_attention_bf16_lse(const void *Q, const void *K, const void *V, void *O, float *lse, int B, int N, int H, int D, int ldq,
+                              int ldk, int ldv, int ldo, float scale, hipStream_t stream);
+int launch_attention_bwd_bf16(const void *Q, const void *K, const void *V, const void *O, const void *dO, const float *lse,
+                              void *dQ, void *dK, void *dV, int B, int N, int H, int D, int ldqkv, int ldo, int lddo, int lddqkv,
+                              float scale, hipStream_t stream);
+int launch_transpose_bf16(const void *src, bool src_f32, void *dst, int M, int N, int ld_src, int Mp, int skip_tokens,
+                          float *colsum_part, hipStream_t stream);
+int launch_resid_bwd(const float *dh, const void *z, const float *lam, const float *rowscale, void *dz, void *dzT, int M, int C,
+                     int Mp, float *dlam_part, float *db_part, hipStream_t stream);
+int layernorm_bwd_blocks(int64_t rows);
+int launch_layernorm_bwd(const float *dy, const float *x, const float *g, float *dh, int64_t rows, int C, float eps,
+                         float *dg_part, float *db_part, hipStream_t stream);
+int launch_add_inplace(float *a, const float *b, size_t n, hipStream_t stream);
+int launch_expand_rowscale(const float *drop, float *rowscale, int B, int T, int nvec, hipStream_t stream);
+int launch_embed_bwd_small(const float *dh0, float *dpos, float *dcls, float *dpb, int B, int T, int C, hipStream_t stream);
+int launch_patches_transposed(const float *x, void *out, int B, int in_ch, int img_h, int img_w, int p, int Mp, hipStream_t stream);
+int launch_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                 int step, float grad_scale, hipStream_t stream);
 
 }  // namespace ldit

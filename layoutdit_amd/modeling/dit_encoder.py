@@ -264,6 +264,37 @@ class DiTEncoder(nn.Module):
             self._workspace = ws
         return ws
 
+    # ---- train mode ------------------------------------------------------------------------------------------------
+    def _forward_train(self, pixel_values: torch.Tensor, taps, wants_grad: bool) -> DiTEncoderOutput:
+        """``model.train()`` semantics of HF BeitModel (ref trainer.py:38,206): per-sample stochastic depth on both residual
+        branches (TF:360-378,432-434,440-442) and - when parameters require grad - participation in autograd through
+        ``layoutdit_amd.training`` (C ABI: ldit_vit_forward_train / ldit_vit_backward).  bf16 build only."""
+        from .. import training
+        cfg = self.config
+        if self.compute_dtype != "bf16":
+            raise NotImplementedError("training (backward through the encoder) exists for compute_dtype='bf16' only "
+                                      "(BASELINE configs[2]); freeze the backbone as the reference's commented option does "
+                                      "(dit_backbone.py:74-76), run under torch.no_grad() / .eval(), or build "
+                                      "DiTEncoder(..., compute_dtype='bf16')")
+        x = pixel_values.detach().to(torch.float32).contiguous()
+        L = cfg.num_hidden_layers
+        drop = None
+        if cfg.drop_path_rate > 0.0 and L > 1:
+            drop = training.sample_drop_scales(L, x.shape[0], cfg.drop_path_rate, x.device)
+        if wants_grad:
+            outs = training.encoder_forward_autograd(self, x, taps, drop)
+        else:
+            st = training.flat_state(self, x.shape[2], x.shape[3])
+            st.repack()
+            with torch.no_grad():
+                outs = st.forward(x, taps, drop, st.new_saved(x.shape[0]))
+        hidden: List[Optional[torch.Tensor]] = [None] * (L + 1)
+        for t, o in zip(taps, outs):
+            hidden[t] = o
+        if pixel_values.dtype != torch.float32:
+            hidden = [None if h is None else h.to(pixel_values.dtype) for h in hidden]
+        return DiTEncoderOutput(hidden_states=tuple(hidden), last_hidden_state=hidden[L])
+
     # ---- forward -------------------------------------------------------------------------------------------------
     def forward(self, pixel_values: torch.Tensor, taps: Optional[Sequence[int]] = None,
                 _timing: Optional[dict] = None) -> DiTEncoderOutput:
@@ -277,9 +308,6 @@ class DiTEncoder(nn.Module):
         if not pixel_values.is_cuda:
             raise RuntimeError("DiTEncoder runs only on the GPU through libldit_hip.so; move the input and the module "
                                "to a HIP device (there is no CPU / eager fallback)")
-        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("DiTEncoder is forward-only in this round: freeze the backbone (the option the "
-                                      "reference keeps commented at dit_backbone.py:74-76) or run under torch.no_grad()")
         B, _, H, W = pixel_values.shape
         p = cfg.patch_size
         if H % p or W % p:
@@ -288,6 +316,9 @@ class DiTEncoder(nn.Module):
         if len(taps) > _lib.LDIT_MAX_TAPS:
             raise ValueError(f"at most {_lib.LDIT_MAX_TAPS} hidden states per call")
         device = pixel_values.device
+        wants_grad = torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())
+        if self.training and (wants_grad or self.compute_dtype == "bf16"):
+            return self._forward_train(pixel_values, taps, wants_grad)
         x = pixel_values.detach().to(torch.float32).contiguous()   # fp16 inputs (trainer.py:155) are widened
         with torch.no_grad(), torch.cuda.device(device):
             lib = _lib.load()

@@ -206,3 +206,43 @@ def test_ops_wrappers_take_device_and_stream_from_their_tensors():
     assert lib_calls >= 13
     with pytest.raises(ValueError, match="GPU"):
         ops._device(torch.zeros(1))
+
+
+def test_train_step_layout_and_sizing_are_host_side():
+    """ldit_flat_param_layout / ldit_train_*_bytes: pure host arithmetic.  The flat block is the fp32 packed layout, every
+    parameter of the module has exactly one slot of its size, q|k|v weights are the three consecutive thirds of wqkv."""
+    lib = _lib.load()
+    cfg = cfgs.vit_base()
+    lc = _cfg(cfg)
+    lc.dtype = _lib.DTYPE_BF16
+    L, Cc, F = cfg.num_hidden_layers, cfg.hidden_size, cfg.intermediate_size
+    n = 4 + 14 * L + 1
+    offs = (C.c_int64 * n)()
+    assert lib.ldit_flat_param_layout(C.byref(lc), offs, n) == _lib.LDIT_OK
+    assert lib.ldit_flat_param_layout(C.byref(lc), offs, n - 1) == _lib.LDIT_EINVAL
+    o = list(offs)
+    assert o == sorted(o) and o[0] == 0
+    lc32 = _cfg(cfg)
+    assert o[-1] * 4 == lib.ldit_packed_bytes(C.byref(lc32)) == lib.ldit_flat_param_bytes(C.byref(lc))
+    sizes = [Cc * 768, Cc, Cc, 197 * Cc] + [Cc, Cc, 3 * Cc * Cc, 3 * Cc, Cc * Cc, Cc, Cc, Cc, Cc, F * Cc, F, Cc * F, Cc, Cc] * L
+    assert [b - a for a, b in zip(o, o[1:])] == sizes
+    n_params = sum(int(np.prod(s)) for k, s in synth.param_shapes(cfg).items() if "mask_token" not in k and "pooler" not in k)
+    assert o[-1] == n_params + L * Cc                       # + the zero key-bias third per layer
+    M = 64 * 197
+    assert lib.ldit_train_saved_bytes(C.byref(lc), 64) >= L * M * (2 * 4 * Cc + 2 * (8 * Cc + 2 * F))
+    assert lib.ldit_train_workspace_bytes(C.byref(lc), 64) > 0 and lib.ldit_train_wt_bytes(C.byref(lc)) >= 2 * L * (4 * Cc * Cc + 2 * Cc * F)
+    assert lib.ldit_train_saved_bytes(C.byref(lc32), 64) == 0 and "bf16" in lib.ldit_last_error().decode()      # fp32 build
+    big = _cfg(cfgs.vit_large(), 512, 512)
+    big.dtype = _lib.DTYPE_BF16
+    assert lib.ldit_train_saved_bytes(C.byref(big), 1) == 0 and "256" in lib.ldit_last_error().decode()           # N = 1025
+    # train mode of the module without a GPU fails loudly, it does not fall back
+    from layoutdit_amd import training
+    m = DiTEncoder(cfgs.vit_micro(), compute_dtype="bf16").train()
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(torch.zeros(1, 3, 64, 64))
+    rates = training.drop_path_rates(12, 0.1)
+    assert rates[0] == 0.0 and abs(rates[-1] - 0.1) < 1e-12
+    s = training.sample_drop_scales(12, 64, 0.1, "cpu", torch.Generator().manual_seed(1))
+    assert tuple(s.shape) == (12, 2, 64) and bool((s[0] == 1).all())
+    keep = 1.0 - torch.tensor(rates).view(-1, 1, 1)
+    assert bool(((s == 0) | torch.isclose(s, 1.0 / keep.expand_as(s))).all()) and bool((s == 0).any())

@@ -1,0 +1,336 @@
+"""Train step on the GPU (BASELINE.json configs[2]), through the C ABI.
+
+Per kernel: attention forward-with-LSE / backward, LayerNorm backward, the training epilogues of the bf16 GEMM (fp32
+output, split-K slabs, GELU derivative, pre-activation copy, per-row stochastic-depth factor), fused AdamW - each against a
+float64 torch reference on the SAME bf16-rounded inputs.
+Whole path: every parameter gradient of ``hs = self.dit(x).hidden_states`` for upstream gradients at the taps, against the
+float64 autograd oracle (oracle/vit_oracle_torch.py: train_reference, itself pinned to HF BeitModel's gradients in
+tests/test_oracle_grad_golden.py) and directly against the committed HF gradient goldens g6 / g7 - eval-mode arithmetic and
+train mode with the stochastic-depth factors HF drew.
+
+Tolerance: the backward runs on bf16 operands with fp32 accumulation, like the forward (bf16 gate 2e-2 on
+activations).  Gradients are gated per tensor at relative-L2 <= 3e-2 of the tensor's own norm (measured ~3e-3 .. 1e-2)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import ctypes as C                                        # noqa: E402
+
+from layoutdit_amd import _lib, config as cfgs, synth, training   # noqa: E402
+from layoutdit_amd.modeling import DiTEncoder              # noqa: E402
+from oracle import oracle                                  # noqa: E402
+from oracle.vit_oracle_torch import train_reference        # noqa: E402
+from tests.golden.make_golden_grad import upstream         # noqa: E402
+from tests.util import rel_l2                              # noqa: E402
+
+DEV = "cuda:0"
+BF = torch.bfloat16
+GRAD_TOL = 3e-2
+
+
+def _rand(seed, *shape, scale=1.0):
+    n = int(np.prod(shape))
+    return (scale * synth.normal(seed, 9, n)).astype(np.float32).reshape(shape)
+
+
+def _bf(a):
+    return torch.from_numpy(a).to(BF)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---- attention ----------------------------------------------------------------------------------------------------------
+def _attention_ref(q, k, v, do, H):
+    """float64 reference on bf16-rounded inputs: o, log2-domain lse, dq, dk, dv."""
+    q, k, v, do = (t.to(torch.float64).requires_grad_(t is not do) for t in (q, k, v, do))
+    B, N, HD = q.shape
+    D = HD // H
+    qh, kh, vh = (t.view(B, N, H, D).transpose(1, 2) for t in (q, k, v))
+    s = (qh @ kh.transpose(-1, -2)) * D ** -0.5
+    lse2 = torch.logsumexp(s, dim=-1) / np.log(2.0)
+    o = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, N, HD)
+    (o * do).sum().backward()
+    return o.detach(), lse2.detach(), q.grad, k.grad, v.grad
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 256, 2), (3, 17, 2), (2, 33, 1)])
+def test_attention_forward_lse_and_backward(B, N, H):
+    lib = _lib.load()
+    D, HD = 64, H * 64
+    qkv = _bf(_rand(7, B, N, 3 * HD)).to(DEV)
+    do = _bf(_rand(8, B, N, HD, scale=0.5)).to(DEV)
+    q, k, v = qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:]
+    o = torch.empty((B, N, HD), dtype=BF, device=DEV)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=DEV)
+    _lib.check(lib.ldit_attention_fwd_lse_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, D,
+                                               3 * HD, 3 * HD, 3 * HD, HD, D ** -0.5, _stream()))
+    ro, rl, rdq, rdk, rdv = _attention_ref(q.cpu().float(), k.cpu().float(), v.cpu().float(), do.cpu().float(), H)
+    assert rel_l2(o.float().cpu().numpy(), ro.numpy()) < 6e-3
+    np.testing.assert_allclose(lse.cpu().numpy(), rl.numpy(), atol=2e-3)
+    dqkv = torch.full((B, N, 3 * HD), float("nan"), dtype=BF, device=DEV)
+    _lib.check(lib.ldit_attention_bwd_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                                           dqkv.data_ptr(), dqkv[..., HD:].data_ptr(), dqkv[..., 2 * HD:].data_ptr(), B, N, H, D,
+                                           3 * HD, HD, HD, 3 * HD, D ** -0.5, _stream()))
+    torch.cuda.synchronize()
+    got = dqkv.float().cpu().numpy()
+    assert np.isfinite(got).all()                       # every row of dq | dk | dv was written
+    for name, a, r in (("dq", got[..., :HD], rdq), ("dk", got[..., HD:2 * HD], rdk), ("dv", got[..., 2 * HD:], rdv)):
+        assert rel_l2(a, r.numpy()) < 1.5e-2, name
+
+
+def test_attention_backward_rejects_long_sequences():
+    lib = _lib.load()
+    rc = lib.ldit_attention_bwd_bf16(16, 16, 16, 16, 16, 16, 16, 16, 16, 1, 1025, 1, 64, 192, 64, 64, 192, 0.125, None)
+    assert rc == _lib.LDIT_EUNSUPPORTED and b"256" in lib.ldit_last_error()
+
+
+# ---- LayerNorm backward -----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,Cc", [(394, 768), (5, 192), (3000, 1024), (68, 128)])
+def test_layernorm_backward(rows, Cc):
+    lib = _lib.load()
+    x = _rand(11, rows, Cc) * 2.0 + 0.5
+    x[0] *= 50.0
+    g, dy, dh0 = 1.0 + 0.1 * _rand(12, Cc), _rand(13, rows, Cc), _rand(14, rows, Cc)
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    gt = torch.from_numpy(g).double().requires_grad_(True)
+    bt = torch.zeros(Cc, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.layer_norm(xt, (Cc,), gt, bt, 1e-12)
+    (y * torch.from_numpy(dy).double()).sum().backward()
+    dh = torch.from_numpy(dh0).to(DEV)
+    dg, db = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+    need = lib.ldit_layernorm_bwd_scratch_bytes(rows, Cc)
+    scratch = torch.empty(need, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.ldit_layernorm_bwd_f32(torch.from_numpy(dy).to(DEV).data_ptr(), torch.from_numpy(x).to(DEV).data_ptr(),
+                                          torch.from_numpy(g).to(DEV).data_ptr(), dh.data_ptr(), rows, Cc, 1e-12, dg.data_ptr(),
+                                          db.data_ptr(), scratch.data_ptr(), need, _stream()))
+    assert rel_l2(dh.cpu().numpy(), dh0.astype(np.float64) + xt.grad.numpy()) < 2e-5
+    assert rel_l2(dg.cpu().numpy(), gt.grad.numpy()) < 2e-5
+    assert rel_l2(db.cpu().numpy(), bt.grad.numpy()) < 2e-5
+
+
+# ---- the bf16 GEMM's training epilogues ----------------------------------------------------------------------------------------
+def _ex(x, w, epi, M, N, K, bias=None, lam=None, R=None, Y=None, Ypre=None, rowscale=None, aux=None, splits=1):
+    lib = _lib.load()
+    p = lambda t: None if t is None else t.data_ptr()       # noqa: E731
+    _lib.check(lib.ldit_linear_bf16_ex(p(x), K, p(w), p(bias), p(Y), N, M, N, K, epi, p(lam), p(R), None, p(Ypre), p(rowscale),
+                                       p(aux), N, splits, _stream()))
+
+
+@pytest.mark.parametrize("M,N,K", [(394, 768, 256), (34, 512, 128), (1040, 384, 192), (300, 200, 64)])
+def test_linear_bf16_training_epilogues(M, N, K):
+    x, w, b = _bf(_rand(20, M, K)), _bf(_rand(21, N, K, scale=0.05)), torch.from_numpy(_rand(22, N, scale=0.1))
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    ref = x.double() @ w.double().T + b.double()
+    # fp32 output
+    y = torch.empty((M, N), device=DEV)
+    _ex(xd, wd, _lib.EPI_F32, M, N, K, bias=bd, Y=y)
+    assert rel_l2(y.cpu().numpy(), ref.numpy()) < 1e-5
+    # GELU forward with the pre-activation copy
+    g, pre = torch.empty((M, N), dtype=BF, device=DEV), torch.empty((M, N), dtype=BF, device=DEV)
+    _ex(xd, wd, _lib.EPI_BIAS_GELU, M, N, K, bias=bd, Y=g, Ypre=pre)
+    assert rel_l2(pre.float().cpu().numpy(), ref.numpy()) < 3e-3
+    assert rel_l2(g.float().cpu().numpy(), torch.nn.functional.gelu(ref).numpy()) < 3e-3
+    # LayerScale + residual with per-row stochastic-depth factors and the pre-LayerScale copy
+    lam = torch.from_numpy(np.abs(_rand(23, N)) * 0.3 + 0.05)
+    r = torch.from_numpy(_rand(24, M, N))
+    rs = torch.from_numpy((np.arange(M) % 3 != 0).astype(np.float32) / 0.9)
+    h, z = r.clone().to(DEV), torch.empty((M, N), dtype=BF, device=DEV)
+    _ex(xd, wd, _lib.EPI_SCALE_RESID, M, N, K, bias=bd, lam=lam.to(DEV), R=h, Y=h, Ypre=z, rowscale=rs.to(DEV))
+    want = r.double() + rs.double()[:, None] * lam.double() * ref
+    assert rel_l2(h.cpu().numpy(), want.numpy()) < 1e-5
+    assert rel_l2(z.float().cpu().numpy(), ref.numpy()) < 3e-3
+    # GELU derivative folded into a dgrad
+    a = _bf(_rand(25, M, N, scale=1.5))
+    d = torch.empty((M, N), dtype=BF, device=DEV)
+    _ex(xd, wd, _lib.EPI_GELU_BWD, M, N, K, Y=d, aux=a.to(DEV))
+    at = a.double().requires_grad_(True)
+    torch.nn.functional.gelu(at).sum().backward()
+    assert rel_l2(d.float().cpu().numpy(), ((ref - b.double()) * at.grad).numpy()) < 4e-3
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(768, 512, 1344, 7), (128, 768, 128, 2), (384, 256, 12608, 16)])
+def test_linear_bf16_split_k_slabs(M, N, K, splits):
+    """wgrad shape: few output tiles, long K - K is split over workgroups into fp32 slabs, summed in a fixed order."""
+    lib = _lib.load()
+    x, w = _bf(_rand(30, M, K, scale=0.3)), _bf(_rand(31, N, K, scale=0.3))
+    slabs = torch.full((splits, M, N), float("nan"), device=DEV)
+    _ex(x.to(DEV), w.to(DEV), _lib.EPI_F32, M, N, K, Y=slabs, splits=splits)
+    out = torch.empty((M, N), device=DEV)
+    _lib.check(lib.ldit_reduce_slabs_f32(slabs.data_ptr(), out.data_ptr(), M * N, splits, _stream()))
+    assert rel_l2(out.cpu().numpy(), (x.double() @ w.double().T).numpy()) < 1e-5
+    out2 = torch.empty((M, N), device=DEV)
+    _ex(x.to(DEV), w.to(DEV), _lib.EPI_F32, M, N, K, Y=slabs, splits=splits)
+    _lib.check(lib.ldit_reduce_slabs_f32(slabs.data_ptr(), out2.data_ptr(), M * N, splits, _stream()))
+    assert torch.equal(out, out2)                        # no atomics: bit-reproducible
+    rc = lib.ldit_linear_bf16_ex(16, 64, 16, None, 16, 64, 64, 64, 64, _lib.EPI_BIAS, None, None, None, None, None, None, 0, 2, None)
+    assert rc == _lib.LDIT_EINVAL                        # split-K needs the fp32 slab epilogue
+
+
+# ---- AdamW -----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_fused_adamw_matches_torch(wd):
+    lib = _lib.load()
+    n = 4 * 1000 + 4
+    p0, grads = _rand(40, n), [_rand(41 + i, n, scale=0.1) for i in range(3)]
+    ref = torch.nn.Parameter(torch.from_numpy(p0.copy()).double())
+    opt = torch.optim.AdamW([ref], lr=1e-2, weight_decay=wd, betas=(0.9, 0.999), eps=1e-8)
+    p = torch.from_numpy(p0.copy()).to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for i, g in enumerate(grads):
+        ref.grad = torch.from_numpy(g).double() * 0.5
+        opt.step()
+        gd = torch.from_numpy(g).to(DEV)
+        _lib.check(lib.ldit_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-2, 0.9, 0.999, 1e-8, wd,
+                                       i + 1, 0.5, _stream()))
+    assert rel_l2(p.cpu().numpy(), ref.detach().numpy()) < 1e-6
+    assert lib.ldit_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-2, 0.9, 0.999, 1e-8, wd, 0, 1.0,
+                               _stream()) == _lib.LDIT_EINVAL
+
+
+# ---- whole path -----------------------------------------------------------------------------------------------------------------------
+_KEYMAP = {"ln1_w": "layernorm_before.weight", "ln1_b": "layernorm_before.bias", "wq": "attention.attention.query.weight",
+           "wk": "attention.attention.key.weight", "wv": "attention.attention.value.weight",
+           "bq": "attention.attention.query.bias", "bv": "attention.attention.value.bias",
+           "wo": "attention.output.dense.weight", "bo": "attention.output.dense.bias", "lam1": "lambda_1",
+           "ln2_w": "layernorm_after.weight", "ln2_b": "layernorm_after.bias", "w1": "intermediate.dense.weight",
+           "b1": "intermediate.dense.bias", "w2": "output.dense.weight", "b2": "output.dense.bias", "lam2": "lambda_2"}
+_EMB = {"patch_w": "embeddings.patch_embeddings.projection.weight", "patch_b": "embeddings.patch_embeddings.projection.bias",
+        "cls": "embeddings.cls_token", "pos": "embeddings.position_embeddings"}
+
+
+def _hf_name(short: str) -> str:
+    if short in _EMB:
+        return _EMB[short]
+    l, k = short.split(".")
+    return f"encoder.layer.{l}.{_KEYMAP[k]}"
+
+
+def _grads_through_autograd(cfg, w, x, dtaps, scales, monkeypatch):
+    m = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(w).to(DEV).train()
+    if scales is not None:
+        monkeypatch.setattr(training, "sample_drop_scales", lambda *a, **k: torch.from_numpy(scales).to(DEV).contiguous())
+    else:
+        m.config.drop_path_rate = 0.0
+    out = m(torch.from_numpy(x).to(DEV))
+    loss = sum((out.hidden_states[t] * torch.from_numpy(d).to(DEV)).sum() for t, d in zip(cfg.taps, dtaps))
+    loss.backward()
+    torch.cuda.synchronize()
+    st = m._flat_state
+    grads = {_hf_name(name): p.grad.detach().cpu().numpy() for name, p, _, _ in st.named}
+    taps = [out.hidden_states[t].detach().cpu().numpy() for t in cfg.taps]
+    assert m.embeddings.mask_token.grad is None and m.pooler.layernorm.weight.grad is None      # inert parameters
+    return taps, grads, m
+
+
+@pytest.mark.parametrize("name,geom", [("g6_grad_micro.npz", "micro"), ("g7_grad_tiny.npz", "tiny")])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_parameter_gradients_vs_oracle_and_hf_golden(golden_dir, monkeypatch, name, geom, mode):
+    g = np.load(os.path.join(golden_dir, name))
+    cfg = cfgs.GEOMETRIES[geom]()
+    B, size = int(g["geometry"][6]), int(g["geometry"][7])
+    wseed, xseed, gseed = (int(v) for v in g["seeds"])
+    w = synth.synth_weights(cfg, wseed)
+    x = synth.synth_images(B, size, size, seed=xseed, kind="uniform" if size < 224 else "doc")
+    dtaps = upstream(cfg, B, cfg.tokens(size, size), gseed)
+    scales = None if mode == "eval" else g["train_drop_scales"]
+    taps, grads, _ = _grads_through_autograd(cfg, w, x, dtaps, scales, monkeypatch)
+    ref_taps, ref = train_reference(cfg, w, x, dtaps, drop_scales=scales)
+    for a, r in zip(taps, ref_taps):
+        assert rel_l2(a, r) < 2e-2
+    stride = int(g["stride"][0])
+    worst = {}
+    for k, r in ref.items():
+        if k.endswith("mask_token"):
+            continue
+        got = grads[k]
+        assert got.shape == r.shape, k
+        e = rel_l2(got, r)
+        worst[k.split(".")[-2] + "." + k.split(".")[-1]] = max(worst.get(k.split(".")[-2] + "." + k.split(".")[-1], 0.0), e)
+        assert e < GRAD_TOL, (k, e)
+        hf = g[f"{mode}_grad/{k}"]                       # HF BeitModel's own gradient, strided sample
+        assert rel_l2(got.reshape(-1)[::stride], hf) < GRAD_TOL, (k, "vs HF golden")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/grad_parity_{geom}_{mode}.txt", "w") as f:
+        for k, e in sorted(worst.items(), key=lambda kv: -kv[1]):
+            f.write(f"{k:40s} {e:.3e}\n")
+
+
+def test_key_bias_slot_and_reproducibility(monkeypatch):
+    """The fused bias gradient's key third is exactly zero (BEiT has no key bias, TF:306) and two backward passes over the
+    same inputs give bit-identical gradients (no atomics anywhere in the backward)."""
+    cfg = cfgs.vit_micro()
+    w = synth.synth_weights(cfg, 3)
+    x = synth.synth_images(4, 64, 64, seed=5, kind="uniform")
+    dtaps = upstream(cfg, 4, cfg.tokens(64, 64), 9)
+    _, g1, m = _grads_through_autograd(cfg, w, x, dtaps, None, monkeypatch)
+    st = m._flat_state
+    Cc = cfg.hidden_size
+    flat1 = st.grads.clone()
+    for l in range(cfg.num_hidden_layers):
+        off = st.offsets[4 + 14 * l + 3]
+        assert bool((st.grads[off + Cc: off + 2 * Cc] == 0).all())
+    for p in m.parameters():
+        p.grad = None
+    out = m(torch.from_numpy(x).to(DEV))
+    sum((out.hidden_states[t] * torch.from_numpy(d).to(DEV)).sum() for t, d in zip(cfg.taps, dtaps)).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(st.grads, flat1)
+
+
+def test_reference_style_loop_with_torch_adamw_and_fused_step_agree(monkeypatch):
+    """Drop-in: the reference's loop shape - loss.backward() then torch.optim.AdamW(lr 1e-4, wd 0).step()
+    (ref trainer.py:62-68,169-180) - on DiTEncoder in train mode, against TrainStep's fused AdamW on the same gradients."""
+    cfg = cfgs.vit_micro()
+    cfg.drop_path_rate = 0.0
+    w = synth.synth_weights(cfg, 3)
+    x = torch.from_numpy(synth.synth_images(4, 64, 64, seed=5, kind="uniform")).to(DEV)
+    dt = [torch.from_numpy(d).to(DEV) for d in upstream(cfg, 4, cfg.tokens(64, 64), 9)]
+    a = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(w).to(DEV).train()
+    opt = torch.optim.AdamW([p for p in a.parameters()], lr=1e-3, weight_decay=0.0)
+    b = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(w).to(DEV).train()
+    fused = training.TrainStep(b, lr=1e-3, weight_decay=0.0, dtaps=dt, drop_path_rate=0.0, img_size=(64, 64))
+    for _ in range(3):
+        opt.zero_grad()
+        out = a(x)
+        sum((out.hidden_states[t] * d).sum() for t, d in zip(cfg.taps, dt)).backward()
+        opt.step()
+        fused.step(x)
+    torch.cuda.synchronize()
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert rel_l2(sb[k].cpu().numpy(), sa[k].cpu().numpy()) < 1e-5, k
+    moved = rel_l2(sa["encoder.layer.0.intermediate.dense.weight"].cpu().numpy(), w["encoder.layer.0.intermediate.dense.weight"])
+    assert moved > 1e-3                                    # the parameters really were updated
+    # the inference path sees the updated weights (its packed copy is invalidated by the step)
+    b.eval()
+    a.eval()
+    with torch.no_grad():
+        ha, hb = a(x).hidden_states, b(x).hidden_states
+    for t in cfg.taps:
+        assert rel_l2(hb[t].cpu().numpy(), ha[t].cpu().numpy()) < 1e-4
+
+
+def test_train_mode_without_grad_applies_stochastic_depth(monkeypatch):
+    cfg = cfgs.vit_micro()
+    w = synth.synth_weights(cfg, 3)
+    x = synth.synth_images(4, 64, 64, seed=5, kind="uniform")
+    scales = np.ones((cfg.num_hidden_layers, 2, 4), dtype=np.float32)
+    scales[1, 0, 2] = 0.0
+    scales[2, 1, 0] = 1.0 / 0.9
+    monkeypatch.setattr(training, "sample_drop_scales", lambda *a, **k: torch.from_numpy(scales).to(DEV).contiguous())
+    m = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(w).to(DEV).train()
+    with torch.no_grad():
+        hs = m(torch.from_numpy(x).to(DEV)).hidden_states
+    ref, _ = train_reference(cfg, w, x, [np.zeros((4, 17, 128), np.float32)] * 4, drop_scales=scales)
+    for t, r in zip(cfg.taps, ref):
+        assert rel_l2(hs[t].cpu().numpy(), r) < 2e-2
+    m32 = DiTEncoder(cfg).load_numpy(w).to(DEV).train()
+    with pytest.raises(NotImplementedError, match="bf16"):
+        m32(torch.from_numpy(x).to(DEV))
