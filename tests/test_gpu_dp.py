@@ -86,3 +86,61 @@ def test_rccl_control_plane_one_rank():
                PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "rccl-ok" in res.stdout, res.stderr[-2000:]
+
+
+def _train_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from layoutdit_amd import training
+    from layoutdit_amd.modeling import DiTEncoder
+    from tests.golden.make_golden_grad import upstream
+    r = dp.init(backend="gloo")
+    try:
+        cfg = cfgs.vit_micro()
+        total = 4
+        lo, hi = dp.shard_range(total, r.rank, r.world)
+        m = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(synth.synth_weights(cfg, 3)).to("cuda:0").train()
+        x = torch.from_numpy(synth.synth_images(hi - lo, 64, 64, seed=5, kind="uniform", first_index=lo)).to("cuda:0")
+        dt = [torch.from_numpy(d[lo:hi].copy()).to("cuda:0") for d in upstream(cfg, total, cfg.tokens(64, 64), 9)]
+        step = training.TrainStep(m, r, lr=1e-3, weight_decay=0.0, dtaps=dt, drop_path_rate=0.0, img_size=(64, 64))
+        p0 = step.flat_params.cpu().numpy().copy()
+        step.step(x)
+        torch.cuda.synchronize()
+        q.put((r.rank, p0, step.state.grads.cpu().numpy(), step.flat_params.cpu().numpy()))
+    finally:
+        dp.finalize(r)
+
+
+def test_train_step_two_ranks_average_gradients():
+    """DP train step (BASELINE configs[2]) with two ranks on the box's one card (gloo control + data plane for the test;
+    RCCL on a real node): after the per-layer bucketed all-reduce both ranks hold the SAME summed gradient, equal to a
+    single process's gradient on the concatenated batch, and the SAME updated parameters = AdamW on the averaged gradient."""
+    from layoutdit_amd import training
+    from layoutdit_amd.modeling import DiTEncoder
+    from tests.golden.make_golden_grad import upstream
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, p0, g0, n0), (_, _, g1, n1) = got
+    np.testing.assert_array_equal(g0, g1)                 # all-reduced gradient identical on both ranks
+    np.testing.assert_array_equal(n0, n1)                 # ... hence identical replicas after the step
+    cfg = cfgs.vit_micro()
+    m = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(synth.synth_weights(cfg, 3)).to("cuda:0").train()
+    x = torch.from_numpy(synth.synth_images(4, 64, 64, seed=5, kind="uniform")).to("cuda:0")
+    dt = [torch.from_numpy(d).to("cuda:0") for d in upstream(cfg, 4, cfg.tokens(64, 64), 9)]
+    single = training.TrainStep(m, None, lr=1e-3, weight_decay=0.0, dtaps=dt, drop_path_rate=0.0, img_size=(64, 64))
+    single.step(x)
+    full = single.state.grads.cpu().numpy().astype(np.float64)
+    err = np.linalg.norm(g0.astype(np.float64) - full) / np.linalg.norm(full)
+    assert err < 1e-4, err                                # same arithmetic up to the order of the fp32 sums over the batch
+    # AdamW (step 1) on the AVERAGED gradient, float64 on the host
+    g = g0.astype(np.float64) / world
+    mo, vo = 0.1 * g, 0.001 * g * g
+    want = p0.astype(np.float64) - (1e-3 / 0.1) * mo / (np.sqrt(vo) / np.sqrt(0.001) + 1e-8)
+    assert np.abs(n0 - want).max() < 2e-6
