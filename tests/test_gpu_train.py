@@ -300,16 +300,22 @@ def test_reference_style_loop_with_torch_adamw_and_fused_step_agree(monkeypatch)
     opt = torch.optim.AdamW([p for p in a.parameters()], lr=1e-3, weight_decay=0.0)
     b = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(w).to(DEV).train()
     fused = training.TrainStep(b, lr=1e-3, weight_decay=0.0, dtaps=dt, drop_path_rate=0.0, img_size=(64, 64))
-    for _ in range(3):
+    for it in range(3):
         opt.zero_grad()
         out = a(x)
         sum((out.hidden_states[t] * d).sum() for t, d in zip(cfg.taps, dt)).backward()
         opt.step()
         fused.step(x)
+        if it == 0:
+            # same gradients bit for bit -> the two optimizers differ only in the rounding of lr / (1 - beta1^t)
+            assert torch.equal(a._flat_state.grads, fused.state.grads)
+            assert float((a._flat_state.params - fused.state.params).abs().max()) < 2.5e-7      # <= 2 ulp of |p| < 2
     torch.cuda.synchronize()
     sa, sb = a.state_dict(), b.state_dict()
     for k in sa:
-        assert rel_l2(sb[k].cpu().numpy(), sa[k].cpu().numpy()) < 1e-5, k
+        # three steps: the 1-ulp parameter differences of step 1 perturb later gradients, and Adam's sign-like early steps
+        # amplify that on near-zero gradient entries (cls / pos): agreement to 1e-3 of the tensor, not bit level
+        assert rel_l2(sb[k].cpu().numpy(), sa[k].cpu().numpy()) < 1e-3, k
     moved = rel_l2(sa["encoder.layer.0.intermediate.dense.weight"].cpu().numpy(), w["encoder.layer.0.intermediate.dense.weight"])
     assert moved > 1e-3                                    # the parameters really were updated
     # the inference path sees the updated weights (its packed copy is invalidated by the step)
