@@ -63,7 +63,7 @@ enum ldit_epilogue {
     LDIT_EPI_SCALE_RESID = 2,/* Y = R + lam (.) (X W^T + b)           TF:432-434 and TF:440-442 (LayerScale + residual) */
     /* train step, ldit_linear_bf16_ex only: */
     LDIT_EPI_F32 = 4,        /* Y fp32 = X W^T (+ b)                  dgrad into LayerNorm backward; wgrad (split-K slabs) */
-    LDIT_EPI_GELU_BWD = 5    /* Y bf16 = (X W^T) (.) gelu'(aux)       dgrad of fc2 folded with the GELU derivative */
+    LDIT_EPI_GELU_BWD = 5    /* Y bf16 = (X W^T) (.) aux              dgrad of fc2 times the saved GELU derivative */
 };
 
 typedef void *ldit_stream;
@@ -246,19 +246,21 @@ size_t ldit_train_saved_bytes(const ldit_cfg *cfg, int32_t batch);
 size_t ldit_train_workspace_bytes(const ldit_cfg *cfg, int32_t batch);
 size_t ldit_train_wt_bytes(const ldit_cfg *cfg);
 
-/* flat fp32 parameters -> the bf16 packed block ldit_vit_forward[_train] streams from (as ldit_pack_weights would build it)
- * + transposed bf16 copies of the four matrices per layer for the dgrad GEMMs.  Call after every optimizer step. */
+/* flat fp32 parameters -> bf16 copies of the four matrices per layer at their offsets of the bf16 packed block (the
+ * forward's and the wgrad's operand layout; the fp32 vectors of that block are NOT filled: the train-step entry points
+ * read them from the flat block) + their transposed bf16 copies for the dgrad GEMMs.  One read of every matrix.
+ * Call after every optimizer step. */
 int ldit_pack_train(const ldit_cfg *cfg, const void *flat_params, void *packed, size_t packed_bytes, void *wT, size_t wt_bytes,
                     ldit_stream stream);
 
 /* Training forward: as ldit_vit_forward, and keeps in `saved` what the backward needs (LayerNorm inputs and outputs, q|k|v,
- * the attention output and its log-sum-exp, the pre-LayerScale branch outputs, the pre-GELU and post-GELU MLP hidden).
+ * the attention output and its log-sum-exp, the pre-LayerScale branch outputs, the MLP hidden after GELU and the GELU derivative at its pre-activation).
  * drop_scales: device fp32 [layers][2][batch] or NULL - stochastic depth (TF:360-378,432-434,440-442): the factor the
  * residual branch (0 = attention, 1 = MLP) of a layer is multiplied with for each sample, 0 or 1 / keep_prob; drawing
  * them is the caller's job.  ms / launches: as ldit_vit_forward_timed (both NULL = plain enqueue, capturable). */
-int ldit_vit_forward_train(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batch, void *const *tap_out,
-                           const void *drop_scales, void *saved, size_t saved_bytes, ldit_stream stream, double *ms,
-                           int64_t *launches);
+int ldit_vit_forward_train(const ldit_cfg *cfg, const void *packed, const void *flat_params, const void *x, int32_t batch,
+                           void *const *tap_out, const void *drop_scales, void *saved, size_t saved_bytes, ldit_stream stream,
+                           double *ms, int64_t *launches);
 
 /* Backward through stages stage_hi .. stage_lo (stage l >= 1 = encoder layer l, stage 0 = embeddings); a full backward is
  * (layers, 0).  Splitting it into consecutive descending ranges lets the caller start the gradient all-reduce of finished
@@ -266,7 +268,7 @@ int ldit_vit_forward_train(const ldit_cfg *cfg, const void *packed, const void *
  * `workspace` between calls.  dtaps[i] (device fp32 [batch, 1+P, C] or NULL) = gradient of the loss with respect to hidden
  * state cfg->taps[i].  grads: flat fp32 block, OVERWRITTEN (not accumulated) for every parameter of the stages processed.
  * drop_scales: the pointer given to the forward (NULL there = NULL here).  x: the forward's input (patch-embedding wgrad). */
-int ldit_vit_backward(const ldit_cfg *cfg, const void *packed, const void *wT, const void *x, int32_t batch, void *const *dtaps,
+int ldit_vit_backward(const ldit_cfg *cfg, const void *flat_params, const void *wT, const void *x, int32_t batch, void *const *dtaps,
                       const void *drop_scales, const void *saved, size_t saved_bytes, void *grads, size_t grads_bytes,
                       void *workspace, size_t workspace_bytes, int32_t stage_hi, int32_t stage_lo, ldit_stream stream,
                       double *ms, int64_t *launches);
@@ -290,7 +292,8 @@ size_t ldit_layernorm_bwd_scratch_bytes(int64_t rows, int64_t C);
 int ldit_layernorm_bwd_f32(const void *dy, const void *x, const void *gamma, void *dh, int64_t rows, int64_t C, float eps,
                            void *dgamma, void *dbeta, void *scratch, size_t scratch_bytes, ldit_stream stream);
 /* ldit_linear_bf16 with the train step's extras: Ypre (bf16 [M,N], stride ldy) receives X W^T + b before GELU / LayerScale;
- * rowscale (fp32 [M]) multiplies lam per row; aux (bf16 [M,N], stride ldaux) is the pre-activation of LDIT_EPI_GELU_BWD;
+ * (LDIT_EPI_BIAS_GELU: gelu'(X W^T + b) instead); rowscale (fp32 [M]) multiplies lam per row; aux (bf16 [M,N], stride
+ * ldaux) is the factor LDIT_EPI_GELU_BWD multiplies the accumulator with (= that saved gelu');
  * splits > 1 (LDIT_EPI_F32 only): K is cut into `splits` ranges, range s writes its own fp32 slab Y + s M ldy, to be summed
  * with ldit_reduce_slabs_f32. */
 int ldit_linear_bf16_ex(const void *X, int64_t lda, const void *W, const void *bias, void *Y, int64_t ldy, int64_t M, int64_t N,

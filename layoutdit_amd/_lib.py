@@ -74,7 +74,7 @@ SIGNATURES = {
     "ldit_train_workspace_bytes": (_sz, [C.POINTER(LditCfg), _i32]),
     "ldit_train_wt_bytes": (_sz, [C.POINTER(LditCfg)]),
     "ldit_pack_train": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _sz, _vp, _sz, _vp]),
-    "ldit_vit_forward_train": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _i32, C.POINTER(_vp), _vp, _vp, _sz, _vp,
+    "ldit_vit_forward_train": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _vp, _i32, C.POINTER(_vp), _vp, _vp, _sz, _vp,
                                          C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ldit_vit_backward": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _vp, _i32, C.POINTER(_vp), _vp, _vp, _sz, _vp, _sz, _vp, _sz,
                                     _i32, _i32, _vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

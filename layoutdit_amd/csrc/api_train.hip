@@ -57,14 +57,16 @@ SavedMap saved_map(const Geo &g, int batch)
     return m;
 }
 
-constexpr int MAX_SPLITS = 16;
+constexpr int MAX_SPLITS = 8;
 
-// K-splits of a wgrad GEMM with an Mout x Nout output over `nk` k-tiles: enough workgroups for ~one round of 256 CUs
+// K-splits of a wgrad GEMM with an Mout x Nout output over `nk` k-tiles.  The output is a handful of tiles and K = all
+// tokens of the batch, so K is cut until one round of the machine is full: 128 x 128 tiles run two per CU (512 slots).
+// Every split costs one more fp32 slab to write and to sum, hence as few as fill that round, at most 8.
 int pick_splits(int Mout, int Nout, int nk)
 {
-    const long tiles = (long)((Mout + 255) / 256) * ((Nout + 255) / 256);
-    int s = (int)((256 + tiles / 2) / tiles);
-    if (s > MAX_SPLITS) s = MAX_SPLITS;
+    const long tiles = (long)((Mout + 127) / 128) * ((Nout + 127) / 128);
+    int s = (int)(512 / tiles);
+    if (s > 8) s = 8;
     if (s > nk) s = nk;
     if (s < 1) s = 1;
     while (s > 1 && ((nk + s - 1) / s) * (s - 1) >= nk) --s;      // no empty slab
@@ -154,14 +156,14 @@ float *tap_of(const ldit_cfg *cfg, void *const *taps, int hidden_idx)
     return nullptr;
 }
 
-int forward_train(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batch, void *const *tap_out,
-                  const void *drop_scales, void *saved, size_t saved_bytes, hipStream_t stream, Probe &probe)
+int forward_train(const ldit_cfg *cfg, const void *packed, const void *flat_params, const void *x, int32_t batch,
+                  void *const *tap_out, const void *drop_scales, void *saved, size_t saved_bytes, hipStream_t stream, Probe &probe)
 {
     Geo g;
     LDIT_TRY(train_geometry(cfg, g));
     if (batch <= 0) return fail(LDIT_EINVAL, "batch %d must be positive", batch);
-    if (!packed || !x || !saved) return fail(LDIT_EINVAL, "null packed / x / saved pointer");
-    if (!aligned16(packed) || !aligned16(x) || !aligned16(saved)) return fail(LDIT_EINVAL, "pointers must be 16-byte aligned");
+    if (!packed || !flat_params || !x || !saved) return fail(LDIT_EINVAL, "null packed / flat_params / x / saved pointer");
+    if (!aligned16(packed) || !aligned16(flat_params) || !aligned16(x) || !aligned16(saved)) return fail(LDIT_EINVAL, "pointers must be 16-byte aligned");
     if (cfg->n_taps && !tap_out) return fail(LDIT_EINVAL, "tap_out is null");
     for (int i = 0; i < cfg->n_taps; ++i)
         if (!tap_out[i] || !aligned16(tap_out[i])) return fail(LDIT_EINVAL, "tap_out[%d] is null or misaligned", i);
@@ -169,9 +171,10 @@ int forward_train(const ldit_cfg *cfg, const void *packed, const void *x, int32_
         return fail(LDIT_EUNSUPPORTED, "batch %d: activation index space exceeds 2^31 elements, split the batch", batch);
     const SavedMap sm = saved_map(g, batch);
     if (saved_bytes < sm.total) return fail(LDIT_EWORKSPACE, "saved-activation block %zu bytes < required %zu", saved_bytes, sm.total);
-    const PackedMap pm = packed_map(g, cfg->dtype);
-    const char *P = static_cast<const char *>(packed);
-    auto F32 = [&](size_t off) { return reinterpret_cast<const float *>(P + off); };
+    // matrices: bf16 copies in `packed`; every fp32 vector (and the fp32 patch projection): straight from the flat master
+    const PackedMap pmat = packed_map(g, cfg->dtype), pm = packed_map(g, LDIT_F32);
+    const char *P = static_cast<const char *>(packed), *FP = static_cast<const char *>(flat_params);
+    auto F32 = [&](size_t off) { return reinterpret_cast<const float *>(FP + off); };
     char *S = static_cast<char *>(saved);
     const int M = batch * g.T, C = g.C, F = g.F;
     const size_t act_bytes = (size_t)M * C * 4;
@@ -199,24 +202,24 @@ int forward_train(const ldit_cfg *cfg, const void *packed, const void *x, int32_
     }
     const float scale = 1.0f / sqrtf((float)g.D);
     for (int l = 0; l < g.L; ++l) {
-        const PackedLayer &pl = pm.layer[l];
+        const PackedLayer &pl = pm.layer[l], &ml = pmat.layer[l];
         const SavedLayer &sl = sm.layer[l];
         float *h_in = h_of(l), *h_mid = reinterpret_cast<float *>(S + sl.h_mid), *h_out = h_of(l + 1);
         char *y1 = S + sl.y1, *qkv = S + sl.qkv, *o = S + sl.o, *y2 = S + sl.y2, *gl = S + sl.g;
         float *tap = tap_of(cfg, tap_out, l + 1);
         GemmExtra none{}, x1{}, x2{}, x3{};
         x1.Ypre = S + sl.z1; x1.rowscale = rowscale ? rowscale + (size_t)(2 * l) * M : nullptr;
-        x2.Ypre = S + sl.a1;
+        x2.Ypre = S + sl.a1;                       // gelu'(pre-activation), the backward's factor
         x3.Ypre = S + sl.z2; x3.rowscale = rowscale ? rowscale + (size_t)(2 * l + 1) * M : nullptr;
         LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bf16out(h_in, F32(pl.ln1_w), F32(pl.ln1_b), y1, M, C, cfg->ln_eps, stream));
-        LDIT_TRY(gemm(probe, y1, C, P + pl.wqkv, F32(pl.bqkv), qkv, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, none, stream));
+        LDIT_TRY(gemm(probe, y1, C, P + ml.wqkv, F32(pl.bqkv), qkv, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, none, stream));
         LDIT_RUN(probe, LDIT_K_ATTENTION,
                  launch_attention_bf16_lse(qkv, qkv + 2 * (size_t)C, qkv + 4 * (size_t)C, o, reinterpret_cast<float *>(S + sl.lse),
                                            batch, g.T, g.H, g.D, 3 * C, 3 * C, 3 * C, C, scale, stream));
-        LDIT_TRY(gemm(probe, o, C, P + pl.wo, F32(pl.bo), h_mid, C, M, C, C, EPI_SCALE_RESID, F32(pl.lam1), h_in, nullptr, x1, stream));
+        LDIT_TRY(gemm(probe, o, C, P + ml.wo, F32(pl.bo), h_mid, C, M, C, C, EPI_SCALE_RESID, F32(pl.lam1), h_in, nullptr, x1, stream));
         LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bf16out(h_mid, F32(pl.ln2_w), F32(pl.ln2_b), y2, M, C, cfg->ln_eps, stream));
-        LDIT_TRY(gemm(probe, y2, C, P + pl.w1, F32(pl.b1), gl, F, M, F, C, EPI_BIAS_GELU, nullptr, nullptr, nullptr, x2, stream));
-        LDIT_TRY(gemm(probe, gl, F, P + pl.w2, F32(pl.b2), h_out, C, M, C, F, EPI_SCALE_RESID, F32(pl.lam2), h_mid, tap, x3, stream));
+        LDIT_TRY(gemm(probe, y2, C, P + ml.w1, F32(pl.b1), gl, F, M, F, C, EPI_BIAS_GELU, nullptr, nullptr, nullptr, x2, stream));
+        LDIT_TRY(gemm(probe, gl, F, P + ml.w2, F32(pl.b2), h_out, C, M, C, F, EPI_SCALE_RESID, F32(pl.lam2), h_mid, tap, x3, stream));
         if (tap) LDIT_TRY(copy_taps(l + 1, h_out, tap));
     }
     return LDIT_OK;
@@ -235,28 +238,28 @@ int wgrad(Probe &probe, ReduceJobs &jobs, const void *XT, const void *WT, float 
     return LDIT_OK;
 }
 
-int backward(const ldit_cfg *cfg, const void *packed, const void *wT, const void *x, int32_t batch, void *const *dtaps,
+int backward(const ldit_cfg *cfg, const void *flat_params, const void *wT, const void *x, int32_t batch, void *const *dtaps,
              const void *drop_scales, const void *saved, size_t saved_bytes, void *grads, size_t grads_bytes, void *workspace, size_t ws_bytes,
              int stage_hi, int stage_lo, hipStream_t stream, Probe &probe)
 {
     Geo g;
     LDIT_TRY(train_geometry(cfg, g));
     if (batch <= 0) return fail(LDIT_EINVAL, "batch %d must be positive", batch);
-    if (!packed || !wT || !x || !saved || !grads || !workspace) return fail(LDIT_EINVAL, "backward: null pointer");
-    if (!aligned16(packed) || !aligned16(wT) || !aligned16(x) || !aligned16(saved) || !aligned16(grads) || !aligned16(workspace))
+    if (!flat_params || !wT || !x || !saved || !grads || !workspace) return fail(LDIT_EINVAL, "backward: null pointer");
+    if (!aligned16(flat_params) || !aligned16(wT) || !aligned16(x) || !aligned16(saved) || !aligned16(grads) || !aligned16(workspace))
         return fail(LDIT_EINVAL, "backward: pointers must be 16-byte aligned");
     if (stage_hi > g.L || stage_lo < 0 || stage_lo > stage_hi) return fail(LDIT_EINVAL, "backward: stages [%d, %d] outside [0, %d]", stage_lo, stage_hi, g.L);
     const SavedMap sm = saved_map(g, batch);
     if (saved_bytes < sm.total) return fail(LDIT_EWORKSPACE, "saved-activation block %zu bytes < required %zu", saved_bytes, sm.total);
     const TrainWs wm = train_ws_map(g, batch);
     if (ws_bytes < wm.total) return fail(LDIT_EWORKSPACE, "workspace %zu bytes < required %zu", ws_bytes, wm.total);
-    const PackedMap pm = packed_map(g, cfg->dtype), gm = packed_map(g, LDIT_F32);
+    const PackedMap gm = packed_map(g, LDIT_F32), &pm = gm;      // vectors are read from the flat fp32 master
     if (grads_bytes < gm.total) return fail(LDIT_EWORKSPACE, "gradient block %zu bytes < required %zu", grads_bytes, gm.total);
     const WtMap tm = wt_map(g);
     for (int i = 0; dtaps && i < cfg->n_taps; ++i)
         if (dtaps[i] && !aligned16(dtaps[i])) return fail(LDIT_EINVAL, "backward: dtaps[%d] misaligned", i);
 
-    const char *P = static_cast<const char *>(packed), *WT = static_cast<const char *>(wT), *S = static_cast<const char *>(saved);
+    const char *P = static_cast<const char *>(flat_params), *WT = static_cast<const char *>(wT), *S = static_cast<const char *>(saved);
     char *G = static_cast<char *>(grads), *ws = static_cast<char *>(workspace);
     auto F32 = [&](size_t off) { return reinterpret_cast<const float *>(P + off); };
     auto GR = [&](size_t off) { return reinterpret_cast<float *>(G + off); };
@@ -415,58 +418,43 @@ int ldit_pack_train(const ldit_cfg *cfg, const void *flat_params, void *packed, 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const char *Fp = static_cast<const char *>(flat_params);
     char *P = static_cast<char *>(packed), *T = static_cast<char *>(wT);
-    const size_t C = g.C, F = g.F;
-    auto f32 = [&](size_t dst, size_t src, size_t n) -> int {
-        LDIT_HIP_CHECK(hipMemcpyAsync(P + dst, Fp + src, n * 4, hipMemcpyDeviceToDevice, stream));
-        return LDIT_OK;
+    const int C = g.C, F = g.F;
+    // one pass per matrix: W [rows, cols] fp32 -> bf16 W (forward / wgrad operand layout) and bf16 W^T [cols][rows] (dgrad);
+    // the fp32 vectors are NOT copied: the train-step entry points read them from the flat block itself
+    auto mat = [&](size_t dst, size_t src, int rows, int cols, size_t dstT) -> int {
+        return launch_transpose_bf16(Fp + src, true, T + dstT, rows, cols, cols, rows, 0, nullptr, stream, P + dst);
     };
-    auto mat = [&](size_t dst, size_t src, size_t rows, size_t cols, size_t dstT) -> int {
-        const float *s = reinterpret_cast<const float *>(Fp + src);
-        LDIT_TRY(launch_cvt_bf16(s, P + dst, rows * cols, stream));
-        // W [rows, cols] -> W^T [cols][rows] bf16 (rows is a multiple of 64 in the bf16 build)
-        return launch_transpose_bf16(s, true, T + dstT, (int)rows, (int)cols, (int)cols, (int)rows, 0, nullptr, stream);
-    };
-    LDIT_TRY(f32(pm.patch_w, fm.patch_w, C * g.Kp));
-    LDIT_TRY(f32(pm.patch_b, fm.patch_b, C));
-    LDIT_TRY(f32(pm.cls, fm.cls, C));
-    LDIT_TRY(f32(pm.pos, fm.pos, (size_t)g.T * C));
     for (int l = 0; l < g.L; ++l) {
         const PackedLayer &d = pm.layer[l], &s = fm.layer[l];
         const WtLayer &t = tm.layer[l];
-        LDIT_TRY(f32(d.ln1_w, s.ln1_w, C)); LDIT_TRY(f32(d.ln1_b, s.ln1_b, C));
         LDIT_TRY(mat(d.wqkv, s.wqkv, 3 * C, C, t.wqkvT));
-        LDIT_TRY(f32(d.bqkv, s.bqkv, 3 * C));
         LDIT_TRY(mat(d.wo, s.wo, C, C, t.woT));
-        LDIT_TRY(f32(d.bo, s.bo, C)); LDIT_TRY(f32(d.lam1, s.lam1, C));
-        LDIT_TRY(f32(d.ln2_w, s.ln2_w, C)); LDIT_TRY(f32(d.ln2_b, s.ln2_b, C));
         LDIT_TRY(mat(d.w1, s.w1, F, C, t.w1T));
-        LDIT_TRY(f32(d.b1, s.b1, F));
         LDIT_TRY(mat(d.w2, s.w2, C, F, t.w2T));
-        LDIT_TRY(f32(d.b2, s.b2, C)); LDIT_TRY(f32(d.lam2, s.lam2, C));
     }
     return LDIT_OK;
 }
 
-int ldit_vit_forward_train(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batch, void *const *tap_out,
-                           const void *drop_scales, void *saved, size_t saved_bytes, ldit_stream stream, double *ms,
-                           int64_t *launches)
+int ldit_vit_forward_train(const ldit_cfg *cfg, const void *packed, const void *flat_params, const void *x, int32_t batch,
+                           void *const *tap_out, const void *drop_scales, void *saved, size_t saved_bytes, ldit_stream stream,
+                           double *ms, int64_t *launches)
 {
     Probe probe;
     probe.on = ms && launches;
     probe.stream = static_cast<hipStream_t>(stream);
-    int rc = forward_train(cfg, packed, x, batch, tap_out, drop_scales, saved, saved_bytes, probe.stream, probe);
+    int rc = forward_train(cfg, packed, flat_params, x, batch, tap_out, drop_scales, saved, saved_bytes, probe.stream, probe);
     int rc2 = probe.collect(ms, launches);
     return rc != LDIT_OK ? rc : rc2;
 }
 
-int ldit_vit_backward(const ldit_cfg *cfg, const void *packed, const void *wT, const void *x, int32_t batch, void *const *dtaps,
+int ldit_vit_backward(const ldit_cfg *cfg, const void *flat_params, const void *wT, const void *x, int32_t batch, void *const *dtaps,
                       const void *drop_scales, const void *saved, size_t saved_bytes, void *grads, size_t grads_bytes, void *workspace,
                       size_t workspace_bytes, int32_t stage_hi, int32_t stage_lo, ldit_stream stream, double *ms, int64_t *launches)
 {
     Probe probe;
     probe.on = ms && launches;
     probe.stream = static_cast<hipStream_t>(stream);
-    int rc = backward(cfg, packed, wT, x, batch, dtaps, drop_scales, saved, saved_bytes, grads, grads_bytes, workspace, workspace_bytes, stage_hi,
+    int rc = backward(cfg, flat_params, wT, x, batch, dtaps, drop_scales, saved, saved_bytes, grads, grads_bytes, workspace, workspace_bytes, stage_hi,
                       stage_lo, probe.stream, probe);
     int rc2 = probe.collect(ms, launches);
     return rc != LDIT_OK ? rc : rc2;

@@ -66,19 +66,32 @@ __device__ __forceinline__ void store_rows_via_lds(const f32x16 (&acc)[TM][TN], 
                 const unsigned o = (unsigned)(mw + 32 * i + row) * (unsigned)ldy + n;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], abq[e], biasq[e]);
-                if ((EPI == EPI_BIAS_GELU || EPI == EPI_SCALE_RESID) && x.Ypre) {
+                if (EPI == EPI_SCALE_RESID && x.Ypre) {
                     const epi_bf16x4 pre = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                     *reinterpret_cast<epi_bf16x4 *>(static_cast<__bf16 *>(x.Ypre) + o) = pre;
                 }
                 if (EPI == EPI_BIAS_GELU) {
+                    if (x.Ypre) {
+                        f32x4 gp;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_lp(v[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            float ge, gr;
+                            gelu_and_grad_lp(v[e], ge, gr);
+                            v[e] = ge;
+                            gp[e] = gr;
+                        }
+                        const epi_bf16x4 pre = {(__bf16)gp[0], (__bf16)gp[1], (__bf16)gp[2], (__bf16)gp[3]};
+                        *reinterpret_cast<epi_bf16x4 *>(static_cast<__bf16 *>(x.Ypre) + o) = pre;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_lp(v[e]);
+                    }
                 }
                 if (EPI == EPI_GELU_BWD) {
                     const epi_bf16x4 a = *reinterpret_cast<const epi_bf16x4 *>(
                         static_cast<const __bf16 *>(x.aux) + ((unsigned)(mw + 32 * i + row) * (unsigned)x.ldaux + n));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_lp((float)a[e]);
+                    for (int e = 0; e < 4; ++e) v[e] *= (float)a[e];
                 }
                 if (OUT == EPI_OUT_F32) {
                     if (EPI == EPI_SCALE_RESID) {

@@ -103,20 +103,30 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bias[g][e];
                 if ((EPI == EPI_BIAS_GELU || EPI == EPI_SCALE_RESID) && p.x.Ypre) {
+                    // saved for the backward: the pre-LayerScale value, or the GELU derivative at the pre-activation
+                    f32x4 sv = v;
+                    if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float ge, gr;
+                            gelu_and_grad_lp(v[e], ge, gr);
+                            sv[e] = gr;
+                        }
+                    }
                     bf16_t *yp = static_cast<bf16_t *>(p.x.Ypre);
                     if (MODE != 2) {
-                        const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        const bf16x4 pk = {(bf16_t)sv[0], (bf16_t)sv[1], (bf16_t)sv[2], (bf16_t)sv[3]};
                         *reinterpret_cast<bf16x4 *>(yp + o) = pk;
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (n + e < p.N) yp[o + e] = (bf16_t)v[e];
+                            if (n + e < p.N) yp[o + e] = (bf16_t)sv[e];
                     }
                 }
                 if (EPI == EPI_GELU_BWD) {
                     const bf16_t *ax = static_cast<const bf16_t *>(p.x.aux) + ((unsigned)m * (unsigned)p.x.ldaux + (unsigned)n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= (MODE != 2 || n + e < p.N) ? gelu_grad_lp((float)ax[e]) : 0.0f;
+                    for (int e = 0; e < 4; ++e) v[e] *= (MODE != 2 || n + e < p.N) ? (float)ax[e] : 0.0f;
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -472,9 +482,10 @@ __global__ void __launch_bounds__(512, 2) gemm_bf16_skinny(const GemmArgsH p)
         if (n >= p.N) break;
         float t = (e < 4 ? s0[e] : s1[e - 4]) + (p.bias ? p.bias[n] : 0.0f);
         const size_t o = (size_t)row * p.ldy + n;
-        if ((EPI == EPI_BIAS_GELU || EPI == EPI_SCALE_RESID) && p.x.Ypre) static_cast<bf16_t *>(p.x.Ypre)[o] = (bf16_t)t;
+        if (EPI == EPI_SCALE_RESID && p.x.Ypre) static_cast<bf16_t *>(p.x.Ypre)[o] = (bf16_t)t;
+        if (EPI == EPI_BIAS_GELU && p.x.Ypre) static_cast<bf16_t *>(p.x.Ypre)[o] = (bf16_t)gelu_grad_lp(t);
         if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
-        if (EPI == EPI_GELU_BWD) t *= gelu_grad_lp((float)static_cast<const bf16_t *>(p.x.aux)[(size_t)row * p.x.ldaux + n]);
+        if (EPI == EPI_GELU_BWD) t *= (float)static_cast<const bf16_t *>(p.x.aux)[(size_t)row * p.x.ldaux + n];
         if (EPI == EPI_SCALE_RESID) {
             t = p.x.rowscale ? __builtin_fmaf(p.lam[n] * p.x.rowscale[row], t, p.R[o]) : __builtin_fmaf(p.lam[n], t, p.R[o]);
             static_cast<float *>(p.Y)[o] = t;

@@ -81,6 +81,19 @@ __device__ __forceinline__ float gelu_grad_lp(float v)
     return __builtin_fmaf(v * 0.39894228040143267794f, e, cdf);
 }
 
+// erf-GELU and its derivative from one set of sub-expressions (train forward: the fc1 epilogue stores both)
+__device__ __forceinline__ void gelu_and_grad_lp(float v, float &gelu, float &grad)
+{
+    const float x = __builtin_fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.47047f, x, 1.0f));
+    const float poly = t * __builtin_fmaf(t, __builtin_fmaf(t, 0.7478556f, -0.0958798f), 0.3480242f);
+    const float e = __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);
+    const float er = __builtin_copysignf(__builtin_fmaf(-poly, e, 1.0f), v);
+    const float hv = 0.5f * v;
+    gelu = __builtin_fmaf(hv, er, hv);
+    grad = __builtin_fmaf(v * 0.39894228040143267794f, e, __builtin_fmaf(0.5f, er, 0.5f));
+}
+
 // 4 floats -> 4 fp8 e4m3 (round to nearest even, saturating at +-448), packed little-endian in one dword
 __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d)
 {
@@ -97,13 +110,14 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 enum AMode { A_ROWMAJOR = 0, A_PATCH = 1 };
 enum Epi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_SCALE_RESID = 2, EPI_EMBED = 3,
            EPI_F32 = 4,        // bf16 GEMM only: Y fp32 = acc (+ bias); dgrad into LayerNorm backward, wgrad slabs
-           EPI_GELU_BWD = 5 }; // bf16 GEMM only: Y bf16 = acc * gelu'(aux)   (dgrad of fc2 folded with the GELU derivative)
+           EPI_GELU_BWD = 5 }; // bf16 GEMM only: Y bf16 = acc * aux, aux = gelu'(pre-activation) saved by the forward
 
 // Optional operands of the bf16 GEMM used by the train step (training.hip); all null / 1 for inference.
 struct GemmExtra {
-    void *Ypre = nullptr;              // bf16 [M,N], row stride ldy: acc + bias BEFORE GELU / LayerScale (saved for backward)
+    void *Ypre = nullptr;              // bf16 [M,N], row stride ldy, saved for backward: EPI_SCALE_RESID: acc + bias before
+                                       // LayerScale; EPI_BIAS_GELU: gelu'(acc + bias), the factor of the GELU backward
     const float *rowscale = nullptr;   // fp32 [M]: per-row factor on lam (stochastic depth, TF:360-378), EPI_SCALE_RESID
-    const void *aux = nullptr;         // bf16 [M,N], row stride ldaux: pre-activation for EPI_GELU_BWD
+    const void *aux = nullptr;         // bf16 [M,N], row stride ldaux: EPI_GELU_BWD multiplies the accumulator with it
     int ldaux = 0;
     int splits = 1;                    // EPI_F32: K split into `splits` slabs, slab s at (float*)Y + s * M * ldy
 };
@@ -186,7 +200,7 @@ int launch_attention_bwd_bf16(const void *Q, const void *K, const void *V, const
                               void *dQ, void *dK, void *dV, int B, int N, int H, int D, int ldqkv, int ldo, int lddo, int lddqkv,
                               float scale, hipStream_t stream);
 int launch_transpose_bf16(const void *src, bool src_f32, void *dst, int M, int N, int ld_src, int Mp, int skip_tokens,
-                          float *colsum_part, hipStream_t stream);
+                          float *colsum_part, hipStream_t stream, void *rowmajor_copy = nullptr);
 int launch_resid_bwd(const float *dh, const void *z, const float *lam, const float *rowscale, void *dz, void *dzT, int M, int C,
                      int Mp, float *dlam_part, float *db_part, hipStream_t stream);
 int layernorm_bwd_blocks(int64_t rows);

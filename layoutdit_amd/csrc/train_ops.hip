@@ -27,9 +27,12 @@ __device__ __forceinline__ float wave_sum(float v)
 // finite zeros), n < N.  src row stride lds_, dst row stride Mp (multiple of 64).  SRC_F32: fp32 source (else bf16).
 // `skip`: tokens per image when the source is a [B, 1 + P, C] token tensor whose CLS rows are skipped (m = b P + i ->
 // source row b (P + 1) + 1 + i; 0 = plain rows).  `colsum` (optional): part[blockIdx.y][n] = sum over the tile's rows.
+// `rowmajor` (optional, fp32 sources): bf16 copy of the source in its own layout - weight packing reads a matrix once and
+// writes both the forward's operand copy and the dgrad's transposed copy.
 template <bool SRC_F32>
 __global__ void __launch_bounds__(256) transpose_tile(const void *__restrict__ src, bf16_t *__restrict__ dst, int M, int N,
-                                                      int lds_, int Mp, int skip, float *__restrict__ colsum)
+                                                      int lds_, int Mp, int skip, float *__restrict__ colsum,
+                                                      bf16_t *__restrict__ rowmajor)
 {
     __shared__ float tile[64][65];
     const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, tid = threadIdx.x;
@@ -45,6 +48,11 @@ __global__ void __launch_bounds__(256) transpose_tile(const void *__restrict__ s
                 const float *p = static_cast<const float *>(src) + srow * lds_ + n0 + cb;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) if (n0 + cb + e < N) v[e] = p[e];
+                if (rowmajor) {
+                    bf16_t *r = rowmajor + srow * lds_ + n0 + cb;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) if (n0 + cb + e < N) r[e] = (bf16_t)v[e];
+                }
             } else {
                 const bf16_t *p = static_cast<const bf16_t *>(src) + srow * lds_ + n0 + cb;
                 if (n0 + cb + 16 <= N && ((lds_ | n0) & 7) == 0) {
@@ -374,16 +382,18 @@ __global__ void __launch_bounds__(256) adamw_kernel(float *__restrict__ p, const
     } while (0)
 
 int launch_transpose_bf16(const void *src, bool src_f32, void *dst, int M, int N, int ld_src, int Mp, int skip_tokens,
-                          float *colsum_part, hipStream_t stream)
+                          float *colsum_part, hipStream_t stream, void *rowmajor_copy)
 {
     if (M <= 0 || N <= 0) return fail(LDIT_EINVAL, "transpose: empty problem");
     if (Mp % 64 || Mp < M) return fail(LDIT_EINVAL, "transpose: padded row count %d must be a multiple of 64 and >= %d", Mp, M);
     if (!src || !dst || (reinterpret_cast<uintptr_t>(dst) & 15u)) return fail(LDIT_EINVAL, "transpose: null or misaligned operand");
     const dim3 grid((unsigned)((N + 63) / 64), (unsigned)(Mp / 64));
     if (src_f32)
-        LAUNCH_CHECKED((transpose_tile<true>), grid, dim3(256), 0, stream, src, static_cast<bf16_t *>(dst), M, N, ld_src, Mp, skip_tokens, colsum_part);
+        LAUNCH_CHECKED((transpose_tile<true>), grid, dim3(256), 0, stream, src, static_cast<bf16_t *>(dst), M, N, ld_src, Mp, skip_tokens, colsum_part,
+                       static_cast<bf16_t *>(rowmajor_copy));
     else
-        LAUNCH_CHECKED((transpose_tile<false>), grid, dim3(256), 0, stream, src, static_cast<bf16_t *>(dst), M, N, ld_src, Mp, skip_tokens, colsum_part);
+        LAUNCH_CHECKED((transpose_tile<false>), grid, dim3(256), 0, stream, src, static_cast<bf16_t *>(dst), M, N, ld_src, Mp, skip_tokens, colsum_part,
+                       static_cast<bf16_t *>(nullptr));
     return LDIT_OK;
 }
 

@@ -166,7 +166,7 @@ class FlatState:
         ptrs = (C.c_void_p * max(len(outs), 1))(*[o.data_ptr() for o in outs])
         ms, cnt = self._probe(timing)
         with torch.cuda.device(self.device):
-            _lib.check(lib.ldit_vit_forward_train(C.byref(lcfg), self.packed.data_ptr(), x.data_ptr(), B, ptrs,
+            _lib.check(lib.ldit_vit_forward_train(C.byref(lcfg), self.packed.data_ptr(), self.params.data_ptr(), x.data_ptr(), B, ptrs,
                                                   None if drop_scales is None else drop_scales.data_ptr(), saved.data_ptr(),
                                                   saved.numel(), torch.cuda.current_stream(self.device).cuda_stream, ms, cnt))
         self._collect(timing, ms, cnt)
@@ -182,7 +182,7 @@ class FlatState:
         ws = self.workspace(B)
         ms, cnt = self._probe(timing)
         with torch.cuda.device(self.device):
-            _lib.check(lib.ldit_vit_backward(C.byref(lcfg), self.packed.data_ptr(), self.wt.data_ptr(), x.data_ptr(), B, ptrs,
+            _lib.check(lib.ldit_vit_backward(C.byref(lcfg), self.params.data_ptr(), self.wt.data_ptr(), x.data_ptr(), B, ptrs,
                                              None if drop_scales is None else drop_scales.data_ptr(), saved.data_ptr(),
                                              saved.numel(), self.grads.data_ptr(), self.grads.numel() * 4, ws.data_ptr(),
                                              ws.numel(), stage_hi, stage_lo,
