@@ -138,7 +138,9 @@ def test_train_step_two_ranks_average_gradients():
     single.step(x)
     full = single.state.grads.cpu().numpy().astype(np.float64)
     err = np.linalg.norm(g0.astype(np.float64) - full) / np.linalg.norm(full)
-    assert err < 1e-4, err                                # same arithmetic up to the order of the fp32 sums over the batch
+    # same arithmetic up to (a) the order of the fp32 sums over the batch and (b) the GEMM tiling the row count selects
+    # (34 rows per rank take the split-K skinny kernel, 68 rows the 128 x 128 tiles): a few bf16 roundings flip
+    assert err < 1e-3, err
     # AdamW (step 1) on the AVERAGED gradient, float64 on the host
     g = g0.astype(np.float64) / world
     mo, vo = 0.1 * g, 0.001 * g * g

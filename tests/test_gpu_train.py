@@ -324,7 +324,10 @@ def test_reference_style_loop_with_torch_adamw_and_fused_step_agree(monkeypatch)
     with torch.no_grad():
         ha, hb = a(x).hidden_states, b(x).hidden_states
     for t in cfg.taps:
-        assert rel_l2(hb[t].cpu().numpy(), ha[t].cpu().numpy()) < 1e-4
+        assert rel_l2(hb[t].cpu().numpy(), ha[t].cpu().numpy()) < 2e-3
+    with torch.no_grad():
+        stale = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(w).to(DEV).eval()(x).hidden_states
+    assert rel_l2(hb[cfg.taps[-1]].cpu().numpy(), stale[cfg.taps[-1]].cpu().numpy()) > 1e-2      # ... not the initial ones
 
 
 def test_train_mode_without_grad_applies_stochastic_depth(monkeypatch):
