@@ -227,6 +227,31 @@ int ldit_amax_f32(const void *src, int64_t n, void *out, ldit_stream stream);
 int ldit_preprocess_f32(const void *const *images, const int32_t *heights, const int32_t *widths, int32_t B, int32_t in_ch,
                         float mean, float std, int32_t out_h, int32_t out_w, void *out, ldit_stream stream);
 
+/* Same with fp16 images (the reference's trainer casts images with .half() before the detector's transform,
+ * ref src/layoutdit/training/trainer.py:153-155); arithmetic and output fp32. */
+int ldit_preprocess_f16(const void *const *images, const int32_t *heights, const int32_t *widths, int32_t B, int32_t in_ch,
+                        float mean, float std, int32_t out_h, int32_t out_w, void *out, ldit_stream stream);
+
+/* fp16 <-> fp32 conversion of a pixel batch / of the returned taps for an fp16 caller (round to nearest even), n elements;
+ * the fp16 side 8-byte aligned, the fp32 side 16-byte aligned. */
+int ldit_cast_f16_f32(const void *src, void *dst, int64_t n, ldit_stream stream);
+int ldit_cast_f32_f16(const void *src, void *dst, int64_t n, ldit_stream stream);
+
+/* ---- FPN on top of the taps (ref src/layoutdit/modeling/dit_backbone.py:65-90: torchvision FeaturePyramidNetwork([C]*4,
+ * 256, extra_blocks=LastLevelMaxPool()); torchvision's source is not available offline -> parity unpinned, checked against a
+ * torch restatement of its documented forward).  The 1x1 lateral convolutions run as ldit_linear_f32 on the TOKENS of each
+ * tap (a 1x1 convolution commutes with the bilinear rescale of dit_backbone.py:55-59), then per level:
+ *   ldit_fpn_merge_f32:    inner [B, Gh*s, Gw*s, Ch] (NHWC) = bilinear_s(lat tokens [B, 1+Gh*Gw, Ch]) + nearest(top), top NHWC
+ *                          [B, top_h, top_w, Ch] or NULL (coarsest level);  s in {4, 2, 1, 0.5};  Ch % 4 == 0
+ *   ldit_conv3x3_nhwc_f32: y [B, H, W, Cout] (NHWC) = conv3x3(x [B, H, W, Cin] NHWC, padding 1) + bias as an implicit-im2col
+ *                          fp32 MFMA GEMM; w [Cout, 3, 3, Cin] (= torch weight.permute(0, 2, 3, 1)); Cin % 32 == 0;
+ *                          zeros: >= 128 bytes of device zeros (the padding taps' DMA source).
+ * LastLevelMaxPool (kernel 1, stride 2) is a strided view of the last output, no kernel. */
+int ldit_fpn_merge_f32(const void *lat, const void *top, void *out, int64_t B, int64_t Gh, int64_t Gw, int64_t Ch, float scale,
+                       int64_t top_h, int64_t top_w, ldit_stream stream);
+int ldit_conv3x3_nhwc_f32(const void *x, const void *w, const void *bias, void *y, int64_t B, int64_t H, int64_t W, int64_t Cin,
+                          int64_t Cout, const void *zeros, ldit_stream stream);
+
 /* ==== train step (BASELINE.json configs[2]: ViT-B/16 bs=64 bf16 forward + backward + AdamW) =============
  * Replaces, for the encoder, what the reference's loop runs through torch.autograd and torch.optim:
  *     loss_dict = self.model(images, targets) ; loss.backward() ; optimizer.step()     ref trainer.py:169-180

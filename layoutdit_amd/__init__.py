@@ -15,4 +15,10 @@ def __getattr__(name):
     if name == "DiTBackbone":
         from .modeling.dit_backbone import DiTBackbone
         return DiTBackbone
+    if name == "DiTWithFPN":
+        from .modeling.dit_fpn import DiTWithFPN
+        return DiTWithFPN
+    if name == "DetectorInputTransform":
+        from .modeling.detector_input import DetectorInputTransform
+        return DetectorInputTransform
     raise AttributeError(name)

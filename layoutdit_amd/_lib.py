@@ -67,6 +67,12 @@ SIGNATURES = {
     "ldit_amax_f32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "ldit_preprocess_f32": (C.c_int, [C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i32), _i32, _i32, _f32, _f32, _i32, _i32,
                                       _vp, _vp]),
+    "ldit_preprocess_f16": (C.c_int, [C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i32), _i32, _i32, _f32, _f32, _i32, _i32,
+                                      _vp, _vp]),
+    "ldit_cast_f16_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "ldit_cast_f32_f16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "ldit_fpn_merge_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _i64, _i64, _vp]),
+    "ldit_conv3x3_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     # train step
     "ldit_flat_param_bytes": (_sz, [C.POINTER(LditCfg)]),
     "ldit_flat_param_layout": (C.c_int, [C.POINTER(LditCfg), C.POINTER(_i64), _i32]),

@@ -416,8 +416,55 @@ int ldit_preprocess_f32(const void *const *images, const int32_t *heights, const
     if (B <= 0 || B > 65535 || in_ch <= 0 || out_h <= 0 || out_w <= 0) return fail(LDIT_EINVAL, "preprocess: bad geometry");
     if (!(std > 0.0f)) return fail(LDIT_EINVAL, "preprocess: std must be positive");
     if ((int64_t)B * in_ch * out_h * out_w >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "preprocess: batch exceeds 2^31 elements");
-    return launch_preprocess(reinterpret_cast<const float *const *>(images), heights, widths, B, in_ch, mean, std, out_h, out_w,
-                             static_cast<float *>(out), static_cast<hipStream_t>(stream));
+    return launch_preprocess(images, false, heights, widths, B, in_ch, mean, std, out_h, out_w, static_cast<float *>(out),
+                             static_cast<hipStream_t>(stream));
+}
+
+int ldit_preprocess_f16(const void *const *images, const int32_t *heights, const int32_t *widths, int32_t B, int32_t in_ch,
+                        float mean, float std, int32_t out_h, int32_t out_w, void *out, ldit_stream stream)
+{
+    if (!images || !heights || !widths || !out) return fail(LDIT_EINVAL, "preprocess: null argument");
+    if (B <= 0 || B > 65535 || in_ch <= 0 || out_h <= 0 || out_w <= 0) return fail(LDIT_EINVAL, "preprocess: bad geometry");
+    if (!(std > 0.0f)) return fail(LDIT_EINVAL, "preprocess: std must be positive");
+    if ((int64_t)B * in_ch * out_h * out_w >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "preprocess: batch exceeds 2^31 elements");
+    return launch_preprocess(images, true, heights, widths, B, in_ch, mean, std, out_h, out_w, static_cast<float *>(out),
+                             static_cast<hipStream_t>(stream));
+}
+
+int ldit_fpn_merge_f32(const void *lat, const void *top, void *out, int64_t B, int64_t Gh, int64_t Gw, int64_t Ch, float scale,
+                       int64_t top_h, int64_t top_w, ldit_stream stream)
+{
+    if (B * (Gh * Gw + 1) * Ch >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "fpn_merge: operand exceeds 2^31 elements");
+    return launch_fpn_merge(static_cast<const float *>(lat), static_cast<const float *>(top), static_cast<float *>(out), (int)B,
+                            (int)Gh, (int)Gw, (int)Ch, scale, (int)top_h, (int)top_w, static_cast<hipStream_t>(stream));
+}
+
+int ldit_conv3x3_nhwc_f32(const void *x, const void *w, const void *bias, void *y, int64_t B, int64_t H, int64_t W, int64_t Cin,
+                          int64_t Cout, const void *zeros, ldit_stream stream)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return fail(LDIT_EINVAL, "conv3x3: empty problem");
+    if (B * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31) || Cout * 9 * Cin >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "conv3x3: operand exceeds 2^31 elements");
+    if (!x || !w || !y || !zeros || !aligned16(x) || !aligned16(w) || !aligned16(y) || !aligned16(zeros)) return fail(LDIT_EINVAL, "conv3x3: null or misaligned operand");
+    GemmArgs a{};
+    a.A = static_cast<const float *>(x); a.W = static_cast<const float *>(w); a.Y = static_cast<float *>(y);
+    a.bias = static_cast<const float *>(bias);
+    a.M = (int)(B * H * W); a.N = (int)Cout; a.K = (int)(9 * Cin); a.lda = (int)Cin; a.ldy = (int)Cout;
+    a.conv_h = (int)H; a.conv_w = (int)W; a.conv_c = (int)Cin; a.zeros = static_cast<const float *>(zeros);
+    return launch_gemm(a, EPI_BIAS, A_CONV3, static_cast<hipStream_t>(stream));
+}
+
+int ldit_cast_f16_f32(const void *src, void *dst, int64_t n, ldit_stream stream)
+{
+    if (n < 0 || (n && (!src || !dst))) return fail(LDIT_EINVAL, "cast: null operand");
+    if ((reinterpret_cast<uintptr_t>(src) & 7u) || !aligned16(dst)) return fail(LDIT_EINVAL, "cast: misaligned operand");
+    return launch_cast_f16(src, dst, (size_t)n, true, static_cast<hipStream_t>(stream));
+}
+
+int ldit_cast_f32_f16(const void *src, void *dst, int64_t n, ldit_stream stream)
+{
+    if (n < 0 || (n && (!src || !dst))) return fail(LDIT_EINVAL, "cast: null operand");
+    if (!aligned16(src) || (reinterpret_cast<uintptr_t>(dst) & 7u)) return fail(LDIT_EINVAL, "cast: misaligned operand");
+    return launch_cast_f16(src, dst, (size_t)n, false, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

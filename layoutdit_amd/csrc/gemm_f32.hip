@@ -121,6 +121,7 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(const GemmArgs p)
     // ---- DMA source addresses: this wave moves pieces q = wave + 4u, piece = 8 rows x 128 B -------------------------
     // 32-bit element offsets from the (uniform) operand base: every operand is < 2^31 elements (checked on the host)
     unsigned src[NLD];
+    int yx[NLD];                                        // A_CONV3 only: (y << 16) | x of the lane's pixel, per A piece
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
         const int row = 8 * (wave + 4 * u) + (lane >> 3);
@@ -128,7 +129,11 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(const GemmArgs p)
         if (8 * (wave + 4 * u) < BM) {
             int gm = m0 + row;
             gm = gm < p.M ? gm : p.M - 1;
-            if (AMODE == A_PATCH) {
+            if (AMODE == A_CONV3) {
+                const int hw = p.conv_h * p.conv_w, b = gm / hw, r2 = gm - b * hw, y = r2 / p.conv_w, x = r2 - y * p.conv_w;
+                src[u] = (unsigned)gm * (unsigned)p.conv_c + c * 4;      // centre tap, channel chunk c
+                yx[u] = (y << 16) | x;
+            } else if (AMODE == A_PATCH) {
                 const int b = gm / p.patches, pi = gm - b * p.patches;
                 const int gy = pi / p.gw, gx = pi - gy * p.gw;
                 // per-image channel stride folded in at issue time (depends on k)
@@ -150,7 +155,14 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(const GemmArgs p)
             const int piece = wave + 4 * u;
             const float *opnd = 8 * piece < BM ? p.A : p.W;   // wave-uniform
             const float *g;
-            if (AMODE == A_PATCH && 8 * piece < BM) {
+            if (AMODE == A_CONV3 && 8 * piece < BM) {
+                // k0 lies inside ONE tap (conv_c % 32 == 0): tap (ky, kx) uniform, channel offset c0 uniform
+                const int t = k0 / p.conv_c, c0 = k0 - t * p.conv_c, ky = t / 3, kx = t - 3 * ky;
+                const int yy = (yx[u] >> 16) + ky - 1, xx = (yx[u] & 0xffff) + kx - 1;
+                const bool in = yy >= 0 && yy < p.conv_h && xx >= 0 && xx < p.conv_w;
+                const int shift = ((ky - 1) * p.conv_w + (kx - 1)) * p.conv_c + c0;
+                g = in ? opnd + (int)(src[u] + (unsigned)shift) : p.zeros + 4 * (lane & 7);
+            } else if (AMODE == A_PATCH && 8 * piece < BM) {
                 // k = (ch, dy, dx) with dx fastest; this lane's chunk starts at k0 + 4*c, c recovered from src
                 const int row = 8 * piece + (lane >> 3);
                 const int c = (lane & 7) ^ ((row >> 1) & 7);
@@ -339,6 +351,7 @@ int launch_tiled(const GemmArgs &a, hipStream_t stream)
     if (const char *force = getenv("LDIT_GEMM_TILE")) {
         if (force[0] >= '0' && force[0] <= '3' && force[1] == 0) pick = force[0] - '0';
     }
+    if (AMODE == A_CONV3 && pick == 3) pick = 0;                      // the panel kernel has no implicit-im2col loader
     if (pick == 3) return launch_gemm_panel(a, EPI, AMODE, stream);   // 304 x 128 panel tiling (gemm_panel_f32.hip)
     switch (pick) {
         case 0: return launch_one<5, 2, EPI, AMODE>(a, stream);
@@ -366,10 +379,16 @@ int launch_gemm(const GemmArgs &a, int epi, int amode, hipStream_t stream)
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return fail(LDIT_EINVAL, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     if (a.K % BK) return fail(LDIT_EUNSUPPORTED, "gemm: K=%d must be a multiple of %d", a.K, BK);
     // the kernels keep the offset INSIDE one block tile (<= 320 rows) as a 32-bit byte offset: 320 * 2^21 * 4 < 2^32
-    if (amode == A_ROWMAJOR && (a.lda >= (1 << 21) || a.K >= (1 << 21)))
+    if (amode != A_PATCH && (a.lda >= (1 << 21) || a.K >= (1 << 21)))
         return fail(LDIT_EUNSUPPORTED, "gemm: row stride lda=%d / K=%d must be below 2^21 elements", a.lda, a.K);
     if (!a.A || !a.W || !a.Y) return fail(LDIT_EINVAL, "gemm: null operand");
     if (!aligned16(a.A) || !aligned16(a.W) || (a.lda & 3)) return fail(LDIT_EINVAL, "gemm: operands must be 16-byte aligned");
+    if (amode == A_CONV3) {
+        if (epi != EPI_BIAS) return fail(LDIT_EINVAL, "gemm: the convolution loader feeds the bias epilogue only");
+        if (a.conv_c % BK || a.K != 9 * a.conv_c || !a.zeros || a.conv_h <= 0 || a.conv_w <= 0 || a.conv_h >= 32768 || a.conv_w >= 32768)
+            return fail(LDIT_EUNSUPPORTED, "gemm: 3x3 convolution needs channels %% 32 == 0, K = 9 channels, a zero page");
+        return launch_tiled<EPI_BIAS, A_CONV3>(a, stream);
+    }
     if (amode == A_PATCH) {
         if (epi != EPI_EMBED) return fail(LDIT_EINVAL, "gemm: patch gather only feeds the embedding epilogue");
         if ((a.patch & 3) || (a.img_w & 3)) return fail(LDIT_EUNSUPPORTED, "gemm: patch and image width must be multiples of 4");

@@ -107,7 +107,8 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 }
 
 // ---- GEMM ----------------------------------------------------------------------------------------------------
-enum AMode { A_ROWMAJOR = 0, A_PATCH = 1 };
+enum AMode { A_ROWMAJOR = 0, A_PATCH = 1,
+             A_CONV3 = 2 };   // fp32 general kernel only: implicit im2col of a 3x3 / pad 1 convolution over an NHWC map
 enum Epi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_SCALE_RESID = 2, EPI_EMBED = 3,
            EPI_F32 = 4,        // bf16 GEMM only: Y fp32 = acc (+ bias); dgrad into LayerNorm backward, wgrad slabs
            EPI_GELU_BWD = 5 }; // bf16 GEMM only: Y bf16 = acc * aux, aux = gelu'(pre-activation) saved by the forward
@@ -135,6 +136,10 @@ struct GemmArgs {
     int lda, ldy;        // row strides in floats
     // A_PATCH / EPI_EMBED geometry: row m = (image b, patch gy*gw + gx); k = (ch, dy, dx)
     int img_h, img_w, gw, patches, patch, tokens;
+    // A_CONV3: A = NHWC map [B, conv_h, conv_w, conv_c]; row m = pixel (b, y, x); k = (ky, kx, c); taps outside the map read
+    // `zeros` (>= 128 bytes of device zeros: LDS-DMA has no predication, so padding is a source address)
+    int conv_h, conv_w, conv_c;
+    const float *zeros;
 #ifdef LDIT_GEMM_STAMPS
     unsigned long long *stamps;   // diagnostic build only: 8 words per block (see scripts/gemm_stamps.py)
 #endif
@@ -154,8 +159,11 @@ int launch_attention(const float *Q, const float *K, const float *V, float *O, i
                      int ldk, int ldv, int ldo, float scale, hipStream_t stream);
 int launch_cls_rows(const float *cls, const float *pos, float *out, int B, int tokens, int C, hipStream_t stream);
 int launch_tap_to_map(const float *tap, float *out, int B, int Gh, int Gw, int C, float scale, hipStream_t stream);
-int launch_preprocess(const float *const *images, const int *heights, const int *widths, int B, int in_ch, float mean,
+int launch_preprocess(const void *const *images, bool half_in, const int *heights, const int *widths, int B, int in_ch, float mean,
                       float std, int out_h, int out_w, float *out, hipStream_t stream);
+int launch_cast_f16(const void *src, void *dst, size_t n, bool widen, hipStream_t stream);
+int launch_fpn_merge(const float *lat, const float *top, float *out, int B, int Gh, int Gw, int Ch, float scale, int top_h,
+                     int top_w, hipStream_t stream);
 int launch_gemm_bf16(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
                      const float *lam, const float *R, float *Y2, hipStream_t stream);
 int launch_gemm_bf16_ex(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,

@@ -110,13 +110,16 @@ __global__ void __launch_bounds__(256) tap_to_map_tiled(const float *__restrict_
 // per-channel affine map, so the normalisation is applied to the interpolated value.
 constexpr int PRE_MAX = 48;
 struct PreArgs {
-    const float *img[PRE_MAX];
+    const void *img[PRE_MAX];
     int h[PRE_MAX], w[PRE_MAX];
     float *out;
     int n, in_ch, out_h, out_w, first;
     float mean, inv_std;
 };
 
+// IN = float or _Float16 (the reference's trainer hands fp16 images to the detector, ref trainer.py:153-155); arithmetic and
+// output stay fp32.
+template <typename IN>
 __global__ void __launch_bounds__(256) preprocess_images(const PreArgs a)
 {
     const int owv = (a.out_w + 3) / 4;
@@ -126,13 +129,13 @@ __global__ void __launch_bounds__(256) preprocess_images(const PreArgs a)
     if (idx >= per_img) return;
     const int ch = idx / (a.out_h * owv), rem = idx - ch * (a.out_h * owv), oy = rem / owv, ox0 = (rem - oy * owv) * 4;
     const int h = a.h[i], w = a.w[i];
-    const float *src = a.img[i] + (size_t)ch * h * w;
+    const IN *src = static_cast<const IN *>(a.img[i]) + (size_t)ch * h * w;
     const float sch = (float)h / (float)a.out_h, scw = (float)w / (float)a.out_w;   // F.interpolate(size=...) scale
     float sy = ((float)oy + 0.5f) * sch - 0.5f; sy = sy < 0.f ? 0.f : sy;
     int y0 = (int)sy; y0 = y0 > h - 1 ? h - 1 : y0;
     const int y1 = y0 + (y0 < h - 1);
     const float ly = sy - (float)y0, hy = 1.f - ly;
-    const float *r0 = src + (size_t)y0 * w, *r1 = src + (size_t)y1 * w;
+    const IN *r0 = src + (size_t)y0 * w, *r1 = src + (size_t)y1 * w;
     float *dst = a.out + (((size_t)(a.first + i) * a.in_ch + ch) * a.out_h + oy) * a.out_w + ox0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -141,7 +144,7 @@ __global__ void __launch_bounds__(256) preprocess_images(const PreArgs a)
         int x0 = (int)sx; x0 = x0 > w - 1 ? w - 1 : x0;
         const int x1 = x0 + (x0 < w - 1);
         const float lx = sx - (float)x0, hx = 1.f - lx;
-        const float v = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+        const float v = hy * (hx * (float)r0[x0] + lx * (float)r0[x1]) + ly * (hx * (float)r1[x0] + lx * (float)r1[x1]);
         dst[e] = (v - a.mean) * a.inv_std;
     }
 }
@@ -168,9 +171,45 @@ int launch_tiled_maps(const float *tap, float *out, int B, int Gh, int Gw, int C
     return LDIT_OK;
 }
 
+// fp16 <-> fp32 batch conversion (the encoder computes on fp32 pixels and returns fp32 taps; an fp16 caller gets both ends
+// converted by the library, not by a host-framework cast)
+__global__ void __launch_bounds__(256) widen_f16(const _Float16 *__restrict__ src, float *__restrict__ dst, size_t n)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 v = *reinterpret_cast<const h4 *>(src + i);
+        *reinterpret_cast<f32x4 *>(dst + i) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    } else {
+        for (size_t k = i; k < n; ++k) dst[k] = (float)src[k];
+    }
+}
+
+__global__ void __launch_bounds__(256) narrow_f16(const float *__restrict__ src, _Float16 *__restrict__ dst, size_t n)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + i);
+        *reinterpret_cast<h4 *>(dst + i) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    } else {
+        for (size_t k = i; k < n; ++k) dst[k] = (_Float16)src[k];
+    }
+}
+
 }  // namespace
 
-int launch_preprocess(const float *const *images, const int *heights, const int *widths, int B, int in_ch, float mean,
+int launch_cast_f16(const void *src, void *dst, size_t n, bool widen, hipStream_t stream)
+{
+    if (n == 0) return LDIT_OK;
+    const dim3 grid((unsigned)((n / 4 + 255) / 256 + 1));
+    if (widen) hipLaunchKernelGGL(widen_f16, grid, dim3(256), 0, stream, static_cast<const _Float16 *>(src), static_cast<float *>(dst), n);
+    else hipLaunchKernelGGL(narrow_f16, grid, dim3(256), 0, stream, static_cast<const float *>(src), static_cast<_Float16 *>(dst), n);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+int launch_preprocess(const void *const *images, bool half_in, const int *heights, const int *widths, int B, int in_ch, float mean,
                       float std, int out_h, int out_w, float *out, hipStream_t stream)
 {
     for (int first = 0; first < B; first += PRE_MAX) {
@@ -183,7 +222,8 @@ int launch_preprocess(const float *const *images, const int *heights, const int 
         }
         a.out = out; a.in_ch = in_ch; a.out_h = out_h; a.out_w = out_w; a.first = first; a.mean = mean; a.inv_std = 1.0f / std;
         const int per_img = in_ch * out_h * ((out_w + 3) / 4);
-        hipLaunchKernelGGL(preprocess_images, dim3((per_img + 255) / 256, a.n), dim3(256), 0, stream, a);
+        if (half_in) hipLaunchKernelGGL(preprocess_images<_Float16>, dim3((per_img + 255) / 256, a.n), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(preprocess_images<float>, dim3((per_img + 255) / 256, a.n), dim3(256), 0, stream, a);
         LDIT_HIP_CHECK(hipGetLastError());
     }
     return LDIT_OK;
@@ -219,6 +259,75 @@ int launch_tap_to_map(const float *tap, float *out, int B, int Gh, int Gw, int C
     const size_t total = (size_t)B * Oh * Ow * (C >> 2);
     hipLaunchKernelGGL(tap_to_map, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, tap, out, B, Gh, Gw, C, Oh,
                        Ow, 1.0f / scale);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+}  // namespace ldit
+
+// ---- FPN (ref src/layoutdit/modeling/dit_backbone.py:78-90: torchvision FeaturePyramidNetwork([C]*4, 256, LastLevelMaxPool)) ---
+// One level of the top-down pathway, NHWC:   inner[b, y, x, :] = bilinear_s(lat)[b, y, x, :] + nearest(top)[b, y, x, :]
+// `lat` = the level's 1x1 lateral convolution applied to the TOKENS of its tap, [B, 1 + Gh*Gw, Ch] (CLS row unused): a 1x1
+// convolution and a bilinear resize commute (both linear, the resize's weights sum to one, so the bias passes too), hence
+// the lateral runs on 196 tokens instead of on the 56 x 56 map the reference feeds it - 16x fewer FLOPs at p2 and no
+// 768-channel map is ever materialised.  Resize semantics = F.interpolate(scale_factor=s, mode="bilinear",
+// align_corners=False) of ref dit_backbone.py:55-59; `top` (optional, [B, top_h, top_w, Ch]) is resampled to this level
+// with F.interpolate(size=..., mode="nearest") semantics: src = min(floor(dst * in / out), in - 1).
+namespace ldit {
+namespace {
+
+__global__ void __launch_bounds__(256) fpn_merge_nhwc(const float *__restrict__ lat, const float *__restrict__ top,
+                                                      float *__restrict__ out, int B, int Gh, int Gw, int Ch, int Oh, int Ow,
+                                                      float inv_scale, int top_h, int top_w)
+{
+    const int c4n = Ch >> 2;
+    const size_t total = (size_t)B * Oh * Ow * c4n, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i % c4n);
+    size_t r = i / c4n;
+    const int ox = (int)(r % Ow);
+    r /= Ow;
+    const int oy = (int)(r % Oh), b = (int)(r / Oh);
+    float sy = ((float)oy + 0.5f) * inv_scale - 0.5f, sx = ((float)ox + 0.5f) * inv_scale - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    sx = sx < 0.f ? 0.f : sx;
+    int y0 = (int)sy, x0 = (int)sx;
+    y0 = y0 > Gh - 1 ? Gh - 1 : y0;
+    x0 = x0 > Gw - 1 ? Gw - 1 : x0;
+    const int y1 = y0 + (y0 < Gh - 1), x1 = x0 + (x0 < Gw - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const f32x4 *tok = reinterpret_cast<const f32x4 *>(lat + ((size_t)b * (Gh * Gw + 1) + 1) * Ch) + c4;
+    const f32x4 v00 = tok[(size_t)(y0 * Gw + x0) * c4n], v01 = tok[(size_t)(y0 * Gw + x1) * c4n];
+    const f32x4 v10 = tok[(size_t)(y1 * Gw + x0) * c4n], v11 = tok[(size_t)(y1 * Gw + x1) * c4n];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+    if (top) {
+        int ty = (int)floorf((float)oy * ((float)top_h / (float)Oh)), tx = (int)floorf((float)ox * ((float)top_w / (float)Ow));
+        ty = ty > top_h - 1 ? top_h - 1 : ty;
+        tx = tx > top_w - 1 ? top_w - 1 : tx;
+        const f32x4 t = reinterpret_cast<const f32x4 *>(top)[((size_t)(b * top_h + ty) * top_w + tx) * c4n + c4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += t[e];
+    }
+    reinterpret_cast<f32x4 *>(out)[i] = o;
+}
+
+}  // namespace
+
+int launch_fpn_merge(const float *lat, const float *top, float *out, int B, int Gh, int Gw, int Ch, float scale, int top_h,
+                     int top_w, hipStream_t stream)
+{
+    if (B <= 0 || Gh <= 0 || Gw <= 0 || Ch <= 0 || (Ch & 3)) return fail(LDIT_EINVAL, "fpn_merge: bad geometry");
+    if (!(scale == 4.0f || scale == 2.0f || scale == 1.0f || scale == 0.5f)) return fail(LDIT_EUNSUPPORTED, "fpn_merge: scale %g not in {4,2,1,0.5}", (double)scale);
+    if (!lat || !out || !aligned16(lat) || !aligned16(out) || (top && !aligned16(top))) return fail(LDIT_EINVAL, "fpn_merge: null or misaligned operand");
+    const int Oh = (int)((float)Gh * scale), Ow = (int)((float)Gw * scale);
+    if (Oh <= 0 || Ow <= 0) return fail(LDIT_EINVAL, "fpn_merge: output collapses to zero size");
+    if (top && (top_h <= 0 || top_w <= 0)) return fail(LDIT_EINVAL, "fpn_merge: bad top size");
+    const size_t total = (size_t)B * Oh * Ow * (Ch >> 2);
+    if (total >= (1ull << 31)) return fail(LDIT_EUNSUPPORTED, "fpn_merge: output exceeds 2^31 vectors");
+    hipLaunchKernelGGL(fpn_merge_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, lat, top, out, B, Gh, Gw, Ch, Oh, Ow,
+                       1.0f / scale, top_h, top_w);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }

@@ -276,7 +276,7 @@ class DiTEncoder(nn.Module):
                                       "(BASELINE configs[2]); freeze the backbone as the reference's commented option does "
                                       "(dit_backbone.py:74-76), run under torch.no_grad() / .eval(), or build "
                                       "DiTEncoder(..., compute_dtype='bf16')")
-        x = pixel_values.detach().to(torch.float32).contiguous()
+        x = self._pixels_f32(pixel_values)
         L = cfg.num_hidden_layers
         drop = None
         if cfg.drop_path_rate > 0.0 and L > 1:
@@ -291,8 +291,8 @@ class DiTEncoder(nn.Module):
         hidden: List[Optional[torch.Tensor]] = [None] * (L + 1)
         for t, o in zip(taps, outs):
             hidden[t] = o
-        if pixel_values.dtype != torch.float32:
-            hidden = [None if h is None else h.to(pixel_values.dtype) for h in hidden]
+        if pixel_values.dtype != torch.float32 and not wants_grad:
+            hidden = self._like_input(hidden, pixel_values.dtype)
         return DiTEncoderOutput(hidden_states=tuple(hidden), last_hidden_state=hidden[L])
 
     # ---- forward -------------------------------------------------------------------------------------------------
@@ -319,7 +319,7 @@ class DiTEncoder(nn.Module):
         wants_grad = torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())
         if self.training and (wants_grad or self.compute_dtype == "bf16"):
             return self._forward_train(pixel_values, taps, wants_grad)
-        x = pixel_values.detach().to(torch.float32).contiguous()   # fp16 inputs (trainer.py:155) are widened
+        x = self._pixels_f32(pixel_values)
         with torch.no_grad(), torch.cuda.device(device):
             lib = _lib.load()
             gh, gw = H // p, W // p
@@ -345,6 +345,24 @@ class DiTEncoder(nn.Module):
         hidden: List[Optional[torch.Tensor]] = [None] * (cfg.num_hidden_layers + 1)
         for t, o in zip(taps, outs):
             hidden[t] = o
-        if pixel_values.dtype != torch.float32:
-            hidden = [None if h is None else h.to(pixel_values.dtype) for h in hidden]
+        hidden = self._like_input(hidden, pixel_values.dtype)
         return DiTEncoderOutput(hidden_states=tuple(hidden), last_hidden_state=hidden[cfg.num_hidden_layers])
+
+    @staticmethod
+    def _pixels_f32(pixel_values: torch.Tensor) -> torch.Tensor:
+        """fp32 NCHW contiguous pixels for the kernels.  fp16 batches (the reference's trainer feeds ``.half()`` images under
+        fp16 autocast, ref trainer.py:153-155,168) are widened by the library (ldit_cast_f16_f32), not by a framework cast."""
+        x = pixel_values.detach()
+        if x.dtype == torch.float32:
+            return x.contiguous()
+        if x.dtype == torch.float16:
+            from .. import ops
+            return ops.widen_f16(x.contiguous())
+        raise ValueError(f"pixel_values must be float32 or float16, got {x.dtype}")
+
+    @staticmethod
+    def _like_input(hidden, dtype):
+        if dtype == torch.float32:
+            return hidden
+        from .. import ops
+        return [None if h is None else ops.narrow_f16(h) for h in hidden]

@@ -119,22 +119,52 @@ def tap_to_map(tap: torch.Tensor, gh: int, gw: int, scale: float) -> torch.Tenso
     return out
 
 
-def preprocess(images: Sequence[torch.Tensor], size: int = 224, mean: float = 0.5, std: float = 0.5) -> torch.Tensor:
+def _req16(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float16 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous float16 tensor on the GPU")
+    return t
+
+
+def widen_f16(x: torch.Tensor) -> torch.Tensor:
+    """fp16 -> fp32 on the library's conversion kernel (fp16 pixel batches, ref trainer.py:153-155)."""
+    lib = _lib.load()
+    x = _req16(x, "x")
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    _launch(_device(x), lib.ldit_cast_f16_f32, _ptr(x), _ptr(out), x.numel())
+    return out
+
+
+def narrow_f16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> fp16 (round to nearest even) on the library's conversion kernel."""
+    lib = _lib.load()
+    x = _req(x, "x")
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float16)
+    _launch(_device(x), lib.ldit_cast_f32_f16, _ptr(x), _ptr(out), x.numel())
+    return out
+
+
+def preprocess(images: Sequence[torch.Tensor], size=224, mean: float = 0.5, std: float = 0.5) -> torch.Tensor:
     """The detector's input transform in one kernel (ref src/layoutdit/modeling/model.py:50-54: fixed_size 224,
-    mean = std = 0.5): list of ``[3, h, w]`` images in [0, 1] -> normalised, bilinearly resized ``[B, 3, size, size]``."""
+    mean = std = 0.5): list of ``[3, h, w]`` images in [0, 1] (all fp32 or all fp16) -> normalised, bilinearly resized
+    fp32 ``[B, 3, size, size]``."""
     lib = _lib.load()
     if len(images) == 0:
         raise ValueError("preprocess: empty image list")
-    imgs = [_req(t, f"images[{i}]") for i, t in enumerate(images)]
+    half = images[0].dtype == torch.float16
+    imgs = [(_req16 if half else _req)(t, f"images[{i}]") for i, t in enumerate(images)]
     ch = imgs[0].shape[0]
     if any(t.dim() != 3 or t.shape[0] != ch for t in imgs):
         raise ValueError("preprocess: every image must be [C, h, w] with the same C")
     B = len(imgs)
-    out = torch.empty((B, ch, size, size), device=imgs[0].device, dtype=torch.float32)
+    out_h, out_w = (size, size) if isinstance(size, int) else (int(size[0]), int(size[1]))
+    out = torch.empty((B, ch, out_h, out_w), device=imgs[0].device, dtype=torch.float32)
     ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in imgs])
     hs = (C.c_int32 * B)(*[t.shape[1] for t in imgs])
     ws = (C.c_int32 * B)(*[t.shape[2] for t in imgs])
-    _launch(_device(*imgs), lib.ldit_preprocess_f32, ptrs, hs, ws, B, ch, mean, std, size, size, _ptr(out))
+    if half:
+        _launch(_device(*imgs), lib.ldit_preprocess_f16, ptrs, hs, ws, B, ch, mean, std, out_h, out_w, _ptr(out))
+    else:
+        _launch(_device(*imgs), lib.ldit_preprocess_f32, ptrs, hs, ws, B, ch, mean, std, out_h, out_w, _ptr(out))
     return out
 
 
@@ -239,3 +269,47 @@ def attention_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int
     _launch(_device(q, k, v), lib.ldit_attention_bf16, _ptr(q), _ptr(k), _ptr(v), _ptr(o), B, N, heads, D, q.stride(1), k.stride(1),
                                        v.stride(1), HD, float(D ** -0.5 if scale is None else scale))
     return o
+
+
+def fpn_merge(lat: torch.Tensor, gh: int, gw: int, scale: float, top: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One level of the FPN top-down pathway, NHWC: ``bilinear_scale(lat tokens) + nearest(top)``.
+    ``lat``: [B, 1 + gh*gw, Ch] (lateral 1x1 convolution of a tap's tokens); ``top``: [B, th, tw, Ch] NHWC or None."""
+    lib = _lib.load()
+    lat = _req(lat, "lat")
+    B, T, Ch = lat.shape
+    if T != gh * gw + 1:
+        raise ValueError(f"lat has {T} tokens, grid {gh}x{gw} needs {gh * gw + 1}")
+    if top is not None:
+        top = _req(top, "top")
+    out = torch.empty((B, int(gh * scale), int(gw * scale), Ch), device=lat.device, dtype=torch.float32)
+    th, tw = (0, 0) if top is None else (top.shape[1], top.shape[2])
+    _launch(_device(lat, top), lib.ldit_fpn_merge_f32, _ptr(lat), _ptr(top), _ptr(out), B, gh, gw, Ch, float(scale), th, tw)
+    return out
+
+
+_ZEROS = {}
+
+
+def _zero_page(device: torch.device) -> torch.Tensor:
+    z = _ZEROS.get(device)
+    if z is None:
+        z = torch.zeros(64, dtype=torch.float32, device=device)
+        _ZEROS[device] = z
+    return z
+
+
+def conv3x3_nhwc(x: torch.Tensor, weight_ohwi: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3 / padding 1 convolution of an NHWC map as an implicit-im2col fp32 MFMA GEMM.  ``x``: [B, H, W, Cin];
+    ``weight_ohwi``: [Cout, 3, 3, Cin] (= ``conv.weight.permute(0, 2, 3, 1)``); returns NHWC [B, H, W, Cout]."""
+    lib = _lib.load()
+    x, weight_ohwi = _req(x, "x"), _req(weight_ohwi, "weight_ohwi")
+    B, H, W, Cin = x.shape
+    Cout = weight_ohwi.shape[0]
+    if tuple(weight_ohwi.shape) != (Cout, 3, 3, Cin):
+        raise ValueError(f"weight {tuple(weight_ohwi.shape)} is not [Cout, 3, 3, {Cin}]")
+    if bias is not None:
+        _req(bias, "bias")
+    y = torch.empty((B, H, W, Cout), device=x.device, dtype=torch.float32)
+    _launch(_device(x, weight_ohwi, bias), lib.ldit_conv3x3_nhwc_f32, _ptr(x), _ptr(weight_ohwi), _ptr(bias), _ptr(y), B, H, W, Cin,
+            Cout, _ptr(_zero_page(x.device)))
+    return y

@@ -246,3 +246,19 @@ def test_train_step_layout_and_sizing_are_host_side():
     assert tuple(s.shape) == (12, 2, 64) and bool((s[0] == 1).all())
     keep = 1.0 - torch.tensor(rates).view(-1, 1, 1)
     assert bool(((s == 0) | torch.isclose(s, 1.0 / keep.expand_as(s))).all()) and bool((s == 0).any())
+
+
+def test_detector_input_transform_host_logic():
+    from layoutdit_amd.modeling.detector_input import DetectorInputTransform, resize_boxes
+    b = torch.tensor([[10.0, 20.0, 30.0, 40.0]])
+    assert torch.allclose(resize_boxes(b, (100, 200), (50, 400)), torch.tensor([[20.0, 10.0, 60.0, 20.0]]))
+    t = DetectorInputTransform()
+    assert (t.out_h, t.out_w, t.mean, t.std) == (224, 224, 0.5, 0.5)            # ref model.py:50-54
+    with pytest.raises(ValueError, match="3d"):
+        t([torch.zeros(3, 4)])
+    with pytest.raises(ValueError, match="GPU"):
+        t([torch.zeros(3, 8, 8)])                                            # no CPU path
+    with pytest.raises(NotImplementedError):
+        DetectorInputTransform(image_mean=(0.4, 0.5, 0.6))
+    with pytest.raises(NotImplementedError):
+        DetectorInputTransform(fixed_size=(200, 200))

@@ -1,0 +1,128 @@
+"""The callers either side of the encoder on the GPU, through the C ABI:
+``DiTWithFPN`` (lateral 1x1 on tokens, NHWC top-down merge, implicit-GEMM 3x3, LastLevelMaxPool view) against the torch
+restatement of torchvision's FeaturePyramidNetwork in the REFERENCE's order of operations (oracle/fpn_oracle_torch.py -
+parity unpinned with respect to torchvision itself, its source is not available offline); the detector input transform
+for ragged fp32 / fp16 image lists against ``F.interpolate``; the fp16 entry of the encoder."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import torch.nn.functional as F                      # noqa: E402
+
+from layoutdit_amd import config as cfgs, ops, synth     # noqa: E402
+from layoutdit_amd.modeling import DetectorInputTransform, DiTEncoder, DiTWithFPN    # noqa: E402
+from oracle import oracle                            # noqa: E402
+from oracle.fpn_oracle_torch import backbone_maps, fpn_forward     # noqa: E402
+from tests.util import rel_l2                        # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _rand(seed, *shape, scale=1.0):
+    n = int(np.prod(shape))
+    return (scale * synth.normal(seed, 9, n)).astype(np.float32).reshape(shape)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 7, 7, 256, 256), (1, 56, 56, 256, 256), (3, 5, 9, 64, 96), (1, 1, 1, 32, 32),
+                                            (2, 28, 28, 256, 256)])
+def test_conv3x3_nhwc_implicit_gemm(B, H, W, Cin, Cout):
+    x, w, b = _rand(1, B, H, W, Cin), _rand(2, Cout, Cin, 3, 3, scale=0.05), _rand(3, Cout, scale=0.1)
+    y = ops.conv3x3_nhwc(torch.from_numpy(x).to(DEV), torch.from_numpy(w).permute(0, 2, 3, 1).contiguous().to(DEV),
+                         torch.from_numpy(b).to(DEV))
+    ref = F.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(w).double(), torch.from_numpy(b).double(),
+                   padding=1).permute(0, 2, 3, 1)
+    assert tuple(y.shape) == (B, H, W, Cout)
+    assert rel_l2(y.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("gh,gw,scale,with_top", [(14, 14, 0.5, False), (14, 14, 1.0, True), (14, 14, 2.0, True),
+                                                  (14, 14, 4.0, True), (6, 4, 2.0, True), (5, 7, 0.5, False)])
+def test_fpn_merge_level(gh, gw, scale, with_top):
+    B, Ch = 2, 256
+    lat = _rand(4, B, gh * gw + 1, Ch)
+    oh, ow = int(gh * scale), int(gw * scale)
+    th, tw = max(oh // 2, 1), max(ow // 2, 1)
+    top = _rand(5, B, th, tw, Ch) if with_top else None
+    got = ops.fpn_merge(torch.from_numpy(lat).to(DEV), gh, gw, scale, None if top is None else torch.from_numpy(top).to(DEV))
+    m = torch.from_numpy(lat).double()[:, 1:, :].permute(0, 2, 1).reshape(B, Ch, gh, gw)
+    if scale != 1.0:
+        m = F.interpolate(m, scale_factor=scale, mode="bilinear", align_corners=False)
+    if top is not None:
+        m = m + F.interpolate(torch.from_numpy(top).double().permute(0, 3, 1, 2), size=(oh, ow), mode="nearest")
+    assert tuple(got.shape) == (B, oh, ow, Ch)
+    assert rel_l2(got.cpu().numpy(), m.permute(0, 2, 3, 1).numpy()) < 1e-6
+
+
+def _fpn_weights(m):
+    return {k[len("fpn."):]: v.detach().cpu().numpy() for k, v in m.state_dict().items() if k.startswith("fpn.")}
+
+
+@pytest.mark.parametrize("geom,size,B", [("tiny", 224, 2), ("micro", 64, 3)])
+def test_dit_with_fpn_vs_reference_order_oracle(geom, size, B):
+    cfg = cfgs.GEOMETRIES[geom]()
+    w = synth.synth_weights(cfg, 1)
+    x = synth.synth_images(B, size, size, seed=1234)
+    torch.manual_seed(0)
+    m = DiTWithFPN(config=cfg)
+    m.backbone.dit.load_numpy(w)
+    with torch.no_grad():
+        for p in m.fpn.parameters():                       # non-trivial biases (torchvision's init zeroes them)
+            if p.dim() == 1:
+                p.normal_(0.0, 0.05)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        feats = m(torch.from_numpy(x).to(DEV))
+    g = size // 16
+    assert list(feats) == ["p2", "p3", "p4", "p5", "pool"] and m.out_channels == 256
+    taps, _ = oracle.vit_forward(cfg, w, x)
+    ref = fpn_forward(backbone_maps(taps, g, g), _fpn_weights(m))
+    for k, r in ref.items():
+        a = feats[k]
+        assert tuple(a.shape) == r.shape, k
+        assert rel_l2(a.cpu().numpy(), r) < 2e-5, k
+    assert tuple(feats["pool"].shape[-2:]) == ((g // 2 + 1) // 2, (g // 2 + 1) // 2)
+    # checkpoint surface: torchvision's FPN key names
+    keys = set(m.state_dict())
+    assert {"fpn.inner_blocks.0.0.weight", "fpn.layer_blocks.3.0.bias"} <= keys
+    assert tuple(m.state_dict()["fpn.layer_blocks.0.0.weight"].shape) == (256, 256, 3, 3)
+    m.train()
+    with pytest.raises(NotImplementedError, match="backward"):
+        m(torch.from_numpy(x).to(DEV))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_detector_input_transform_ragged_list(dtype):
+    """ref model.py:45-55,87-88: List[Tensor[3, h, w]] in [0, 1] -> normalised 224 x 224 batch; boxes follow the resize."""
+    sizes = [(300, 200), (224, 224), (97, 411), (640, 480)]
+    imgs = [torch.from_numpy(np.clip(0.5 + 0.3 * _rand(10 + i, 3, h, w), 0, 1)).to(dtype) for i, (h, w) in enumerate(sizes)]
+    boxes = [torch.tensor([[10.0, 20.0, 100.0, 150.0]]) for _ in sizes]
+    t = DetectorInputTransform()
+    il, targets = t([im.to(DEV) for im in imgs], [{"boxes": b.to(DEV), "labels": torch.ones(1)} for b in boxes])
+    assert tuple(il.tensors.shape) == (4, 3, 224, 224) and il.tensors.dtype == torch.float32
+    assert il.image_sizes == [(224, 224)] * 4
+    for i, ((h, w), im) in enumerate(zip(sizes, imgs)):
+        ref = F.interpolate(((im.float() - 0.5) / 0.5)[None], size=(224, 224), mode="bilinear", align_corners=False)[0]
+        assert rel_l2(il.tensors[i].cpu().numpy(), ref.numpy()) < 2e-6, i
+        want = boxes[i] * torch.tensor([224.0 / w, 224.0 / h, 224.0 / w, 224.0 / h])
+        assert torch.allclose(targets[i]["boxes"].cpu(), want)
+    back = t.postprocess([{"boxes": tg["boxes"].clone()} for tg in targets], il.image_sizes, sizes)
+    for b0, b1 in zip(boxes, back):
+        assert torch.allclose(b1["boxes"].cpu(), b0, atol=1e-4)
+
+
+def test_encoder_accepts_fp16_pixels_without_a_host_cast():
+    """ref trainer.py:153-155: the trainer hands fp16 images to the model; the encoder widens them with its own kernel and
+    returns fp16 hidden states."""
+    cfg = cfgs.vit_tiny()
+    m = DiTEncoder(cfg).load_numpy(synth.synth_weights(cfg, 1)).to(DEV).eval()
+    x = torch.from_numpy(synth.synth_images(2, 224, 224, seed=1234)).to(DEV)
+    with torch.no_grad():
+        h32 = m(x.half().float()).hidden_states
+        h16 = m(x.half()).hidden_states
+    for t in cfg.taps:
+        assert h16[t].dtype == torch.float16
+        assert torch.equal(h16[t], h32[t].half())
+    with pytest.raises(ValueError, match="float32 or float16"):
+        m(x.to(torch.bfloat16))
