@@ -14,7 +14,8 @@
 //     quad holds 4 CONSECUTIVE output columns of one row: the whole epilogue (bias, erf-GELU, lambda, residual, tap copy,
 //     position add) runs on float4 and stores 16 B per lane - 4x fewer memory instructions than gemm_f32.hip.
 //   * K-contiguous operands -> LDS by LDS-DMA, 128-B rows, 16-B chunk XOR-swizzled with (row>>1)&7 on the source address
-//     and on the read: conflict-free for both read patterns (row = lane&31 / b128 and row = lane&15 / b64).
+//     and on the read; every fragment read is a ds_read_b128 (the 16-row remainder reads its whole half-chunk and selects
+//     its two floats in registers), conflict-free for both row patterns (row = lane&31 and row = lane&15).
 //   * 8-deep chunks: a 32-row tile lane (r, h) reads k = 8c+4h..+3 (b128), MFMA step s uses k-pair {s, 4+s};
 //     a 16-row tile lane (r, q) reads k = 8c+4(q&1)+(q>>1) and +2, so its two 16x16x4 steps add k0,k4,k1,k5 | k2,k6,k3,k7:
 //     the same product order as the 32x32x2 steps - results are bit-identical across the two shapes.
@@ -243,7 +244,8 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
     const int nk = p.K / BK;
     const int sw32 = (c32 >> 1) & 7, sw16 = (c16 >> 1) & 7;
     const int x32_row = c32 * ROW_BYTES, w32_row = (BM + wave * 32 + c32) * ROW_BYTES;
-    const int x16_row = (32 * T32 + c16) * ROW_BYTES + (q >> 1) * 4, w16_row = (BM + wave * 32 + c16) * ROW_BYTES + (q >> 1) * 4;
+    const int x16_row = (32 * T32 + c16) * ROW_BYTES, w16_row = (BM + wave * 32 + c16) * ROW_BYTES;
+    const bool odd16 = (q >> 1) != 0;     // which two of the four k of its 16-B half-chunk this lane multiplies
 
     struct Frags {
         f32x4 x32[T32 > 0 ? T32 : 1];
@@ -261,12 +263,19 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
             // lane (r, q), element s <- k = 8c + 4(q&1) + (q>>1) + 2s: the 16x16x4 steps then add the products in the
             // order k0,k4,k1,k5 | k2,k6,k3,k7 - the order of the 32x32x2 steps above - so a row's result is bit-identical
             // whichever tile shape it falls into (rows keep their values when the batch composition changes)
+            // Read the whole 16-B half-chunk (ds_read_b128: conflict-free under the (row>>1)&7 swizzle for 16 rows x 2 halves,
+            // like the 32-row reads) and pick the lane's two floats in registers.  Scalar ds_read_b32 of those two floats
+            // put the 32 lanes of a half-wave on 8 banks (every lane reads the same offset inside its chunk): a 4-way
+            // conflict on three reads per chunk = the 41 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the round-1 PMC pass.
             const char *b16 = st + (((c * 2 + (q & 1)) ^ sw16) * 16);
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(b16 + x16_row);
+            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(b16 + w16_row);
+            const f32x4 w1 = *reinterpret_cast<const f32x4 *>(b16 + w16_row + 16 * ROW_BYTES);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                f.x16[s] = *reinterpret_cast<const float *>(b16 + x16_row + 8 * s);
-                f.w16[0][s] = *reinterpret_cast<const float *>(b16 + w16_row + 8 * s);
-                f.w16[1][s] = *reinterpret_cast<const float *>(b16 + w16_row + 16 * ROW_BYTES + 8 * s);
+                f.x16[s] = odd16 ? xv[2 * s + 1] : xv[2 * s];
+                f.w16[0][s] = odd16 ? w0[2 * s + 1] : w0[2 * s];
+                f.w16[1][s] = odd16 ? w1[2 * s + 1] : w1[2 * s];
             }
         }
     };
@@ -285,7 +294,7 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
 
     constexpr int SG_MFMA = 0x8, SG_VMEM = 0x20, SG_DSR = 0x100;
     constexpr int NM = 4 * T32 + (HALF ? 4 : 0);          // MFMAs per 8-deep chunk
-    constexpr int NF = T32 + 1 + (HALF ? 3 : 0);          // LDS fragment reads per chunk (the 16-row ones pair up as read2)
+    constexpr int NF = T32 + 1 + (HALF ? 3 : 0);          // LDS fragment reads per chunk (three b128 for the 16-row remainder)
     constexpr int MPD = (NM - NF) / NLD;                  // MFMAs per DMA piece in chunk 0 (0: tile too small)
     static_assert(NF <= NM, "fewer MFMAs than fragment reads in a chunk");
 

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/{prof,pmc}_<tag> into the tracked files under profiles/: kernel stats CSV, PMC summary text, and
-profiles/<out>_traffic.json (HBM bytes per GEMM launch for bench.py's roofline.traffic).
+"""Turn gpurun_out/{<tag>_bench.json, <tag>_kernel_stats.csv, pmc_<tag>_*} (scripts/prof_config.sh) into the tracked files
+under profiles/: <out>_bench.json, <out>_kernel_stats.csv, <out>_pmc_summary.txt, and one entry of profiles/r02_traffic.json
+(HBM bytes per GEMM launch + PMC MFMA utilisation, keyed by workload, labelled with the commit it was measured on) that
+bench.py reports as roofline.traffic.
+
+    python scripts/make_profile_summary.py <tag> <out> <mode:model:size:batch:dtype> <commit>
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts a wide coalesced read at half its bytes
 (MI355X_MICROARCH.md, HBM section), so read bytes = 2 * FETCH_SIZE * 1024, write bytes = WRITE_SIZE * 1024."""
@@ -12,15 +16,16 @@ import subprocess
 import sys
 from collections import defaultdict
 
-tag, out = sys.argv[1], sys.argv[2]
+tag, out, key, commit = sys.argv[1:5]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = os.path.join(root, "gpurun_out")
 p = os.path.join(root, "profiles")
 os.makedirs(p, exist_ok=True)
-shutil.copy(os.path.join(g, f"prof_{tag}", f"{tag}_kernel_stats.csv"), os.path.join(p, f"{out}_kernel_stats.csv"))
-files = [os.path.join(g, f"pmc_{tag}_{n}", f"{n}_counter_collection.csv") for n in ("sq", "fetch", "write", "lds", "tcc")]
+shutil.copy(os.path.join(g, f"{tag}_kernel_stats.csv"), os.path.join(p, f"{out}_kernel_stats.csv"))
+shutil.copy(os.path.join(g, f"{tag}_bench.json"), os.path.join(p, f"{out}_bench.json"))
+files = [os.path.join(g, f"pmc_{tag}_{n}", f"{n}_counter_collection.csv") for n in ("sq", "fetch", "write", "lds")]
 with open(os.path.join(p, f"{out}_pmc_summary.txt"), "w") as f:
-    for group in ([files[0]], files[1:3], [files[3]], [files[4]]):
+    for group in ([files[0]], files[1:3], [files[3]]):
         f.write(subprocess.run([sys.executable, os.path.join(root, "scripts", "pmc_summary.py")] + group,
                                capture_output=True, text=True).stdout + "\n")
 
@@ -44,10 +49,18 @@ for r in csv.DictReader(open(files[0])):
 busy = sum(sum(v["SQ_VALU_MFMA_BUSY_CYCLES"]) for v in sq.values())
 act = sum(sum(v["GRBM_GUI_ACTIVE"]) for v in sq.values())
 util = busy / (act / 8.0 * 1024.0)
-json.dump({"gemm_hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "launches_sampled": n,
-           "gemm_mfma_util_pmc": util,
-           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py; read = 2*FETCH_SIZE KiB "
-                     "(gfx950 half-count correction), write = WRITE_SIZE KiB; mean over all GEMM dispatches. MFMA util = "
-                     "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs)."},
-          open(os.path.join(p, f"{out}_traffic.json"), "w"), indent=1)
-print(open(os.path.join(p, f"{out}_traffic.json")).read())
+lds = defaultdict(float)
+for r in csv.DictReader(open(files[3])):
+    if "gemm" in r["Kernel_Name"]:
+        lds[r["Counter_Name"]] += float(r["Counter_Value"])
+path = os.path.join(p, "r02_traffic.json")
+table = json.load(open(path)) if os.path.exists(path) else {}
+table[key] = {"commit": commit, "gemm_hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "launches_sampled": n,
+              "gemm_mfma_util_pmc": util,
+              "gemm_lds_bank_conflict_frac": lds["SQ_LDS_BANK_CONFLICT"] / max(lds["SQ_LDS_IDX_ACTIVE"], 1.0),
+              "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py; read = 2*FETCH_SIZE KiB "
+                        "(gfx950 half-count correction), write = WRITE_SIZE KiB; mean over all GEMM dispatches. MFMA util = "
+                        "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); LDS conflicts = SQ_LDS_BANK_CONFLICT / "
+                        "SQ_LDS_IDX_ACTIVE summed over the GEMM dispatches."}
+json.dump(table, open(path, "w"), indent=1)
+print(json.dumps(table[key], indent=1))
