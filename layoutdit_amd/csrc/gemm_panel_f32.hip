@@ -159,7 +159,7 @@ __device__ __forceinline__ void store_panel(const GemmArgs &p, const f32x16 (&ac
     }
 }
 
-template <int T32, bool HALF, int EPI, int AMODE>
+template <int T32, bool HALF, int EPI, int AMODE, bool R16VEC = true>
 __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
 {
     constexpr int BM = 32 * T32 + (HALF ? 16 : 0), BN = BNP, PIECES = (BM + BN) / 8, NLD = (PIECES + 3) / 4;
@@ -268,14 +268,24 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
             // put the 32 lanes of a half-wave on 8 banks (every lane reads the same offset inside its chunk): a 4-way
             // conflict on three reads per chunk = the 41 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the round-1 PMC pass.
             const char *b16 = st + (((c * 2 + (q & 1)) ^ sw16) * 16);
-            const f32x4 xv = *reinterpret_cast<const f32x4 *>(b16 + x16_row);
-            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(b16 + w16_row);
-            const f32x4 w1 = *reinterpret_cast<const f32x4 *>(b16 + w16_row + 16 * ROW_BYTES);
+            if (R16VEC) {
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(b16 + x16_row);
+                const f32x4 w0 = *reinterpret_cast<const f32x4 *>(b16 + w16_row);
+                const f32x4 w1 = *reinterpret_cast<const f32x4 *>(b16 + w16_row + 16 * ROW_BYTES);
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                f.x16[s] = odd16 ? xv[2 * s + 1] : xv[2 * s];
-                f.w16[0][s] = odd16 ? w0[2 * s + 1] : w0[2 * s];
-                f.w16[1][s] = odd16 ? w1[2 * s + 1] : w1[2 * s];
+                for (int s = 0; s < 2; ++s) {
+                    f.x16[s] = odd16 ? xv[2 * s + 1] : xv[2 * s];
+                    f.w16[0][s] = odd16 ? w0[2 * s + 1] : w0[2 * s];
+                    f.w16[1][s] = odd16 ? w1[2 * s + 1] : w1[2 * s];
+                }
+            } else {        // LDIT_PANEL_R16=scalar: the round-1 scalar reads (4-way bank conflict), kept for A/B timing only
+                const int o16 = odd16 ? 4 : 0;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    f.x16[s] = *reinterpret_cast<const float *>(b16 + x16_row + o16 + 8 * s);
+                    f.w16[0][s] = *reinterpret_cast<const float *>(b16 + w16_row + o16 + 8 * s);
+                    f.w16[1][s] = *reinterpret_cast<const float *>(b16 + w16_row + 16 * ROW_BYTES + o16 + 8 * s);
+                }
             }
         }
     };
@@ -393,13 +403,23 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
 #endif
 }
 
+template <int T32, bool HALF, int EPI, int AMODE, bool R16VEC>
+int launch_panel_v(const GemmArgs &a, hipStream_t stream);
+
 template <int T32, bool HALF, int EPI, int AMODE>
 int launch_panel(const GemmArgs &a, hipStream_t stream)
+{
+    static const bool scalar = [] { const char *e = getenv("LDIT_PANEL_R16"); return e && e[0] == 's'; }();
+    return scalar ? launch_panel_v<T32, HALF, EPI, AMODE, false>(a, stream) : launch_panel_v<T32, HALF, EPI, AMODE, true>(a, stream);
+}
+
+template <int T32, bool HALF, int EPI, int AMODE, bool R16VEC>
+int launch_panel_v(const GemmArgs &a, hipStream_t stream)
 {
     constexpr int BM = 32 * T32 + (HALF ? 16 : 0), PIECES = (BM + BNP) / 8, NLD = (PIECES + 3) / 4;
     constexpr int lds = 2 * NLD * 4 * 1024;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BNP - 1) / BNP);
-    auto kern = gemm_panel_f32<T32, HALF, EPI, AMODE>;
+    auto kern = gemm_panel_f32<T32, HALF, EPI, AMODE, R16VEC>;
     static bool attr_set = false;
     if (!attr_set) {
         LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

@@ -154,17 +154,17 @@ def test_error_behaviour():
 
 def test_half_precision_inputs_are_widened_and_outputs_follow_the_input_dtype():
     """The reference's trainer feeds ``.half()`` images (ref src/layoutdit/training/trainer.py:155): the module widens
-    them to fp32 for the kernels and hands the hidden states back in the input's dtype."""
+    them to fp32 with the library's own kernel (ldit_cast_f16_f32) and hands the hidden states back as fp16."""
     cfg = cfgs.vit_micro()
     m, _ = _model(cfg, 7)
     x = torch.from_numpy(synth.synth_images(2, 64, 64, seed=3)).to(DEV)
     with torch.no_grad():
         ref = m(x.half().float()).hidden_states[3]
-        for dt in (torch.float16, torch.bfloat16):
-            out = m(x.half().to(dt)).hidden_states[3]
-            assert out.dtype == dt
-            assert torch.equal(out, ref.to(dt)) or dt == torch.bfloat16     # bf16 re-rounds the fp16-exact pixels
-            assert torch.allclose(out.float(), ref, rtol=2e-2, atol=2e-2)
+        out = m(x.half()).hidden_states[3]
+        assert out.dtype == torch.float16
+        assert torch.equal(out, ref.half())
+        with pytest.raises(ValueError, match="float32 or float16"):       # the two dtypes the reference feeds (fp32 eval, fp16 train)
+            m(x.to(torch.bfloat16))
 
 
 def test_backbone_feature_maps_vs_golden(golden_dir):
