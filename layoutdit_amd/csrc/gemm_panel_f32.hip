@@ -14,8 +14,9 @@
 //     quad holds 4 CONSECUTIVE output columns of one row: the whole epilogue (bias, erf-GELU, lambda, residual, tap copy,
 //     position add) runs on float4 and stores 16 B per lane - 4x fewer memory instructions than gemm_f32.hip.
 //   * K-contiguous operands -> LDS by LDS-DMA, 128-B rows, 16-B chunk XOR-swizzled with (row>>1)&7 on the source address
-//     and on the read; every fragment read is a ds_read_b128 (the 16-row remainder reads its whole half-chunk and selects
-//     its two floats in registers), conflict-free for both row patterns (row = lane&31 and row = lane&15).
+//     and on the read: the b128 reads of the nine 32-row tiles are conflict-free; the scalar reads of the 16-row remainder
+//     are 4-way conflicted (41 % of the LDS-active cycles) but off the critical path - see load_frags for the measured
+//     conflict-free alternative and why it is not the default.
 //   * 8-deep chunks: a 32-row tile lane (r, h) reads k = 8c+4h..+3 (b128), MFMA step s uses k-pair {s, 4+s};
 //     a 16-row tile lane (r, q) reads k = 8c+4(q&1)+(q>>1) and +2, so its two 16x16x4 steps add k0,k4,k1,k5 | k2,k6,k3,k7:
 //     the same product order as the 32x32x2 steps - results are bit-identical across the two shapes.
@@ -263,10 +264,14 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
             // lane (r, q), element s <- k = 8c + 4(q&1) + (q>>1) + 2s: the 16x16x4 steps then add the products in the
             // order k0,k4,k1,k5 | k2,k6,k3,k7 - the order of the 32x32x2 steps above - so a row's result is bit-identical
             // whichever tile shape it falls into (rows keep their values when the batch composition changes)
-            // Read the whole 16-B half-chunk (ds_read_b128: conflict-free under the (row>>1)&7 swizzle for 16 rows x 2 halves,
-            // like the 32-row reads) and pick the lane's two floats in registers.  Scalar ds_read_b32 of those two floats
-            // put the 32 lanes of a half-wave on 8 banks (every lane reads the same offset inside its chunk): a 4-way
-            // conflict on three reads per chunk = the 41 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the round-1 PMC pass.
+            // Two ways to fetch the lane's two floats of its 16-B half-chunk:
+            //  * scalar ds_read_b32 (default): the 32 lanes of a half-wave land on 8 banks (every lane reads the same offset
+            //    inside its chunk) - a 4-way conflict on three reads per chunk, 41 % of SQ_LDS_IDX_ACTIVE in the PMC pass
+            //    (profiles/r01_final_pmc_summary.txt).  The LDS is idle ~85 % of a chunk's 2.4 k MFMA cycles, the reads are
+            //    issued a whole chunk ahead, so the conflict costs nothing measurable;
+            //  * R16VEC: whole half-chunk by ds_read_b128 (conflict-free under the (row>>1)&7 swizzle, like the 32-row reads:
+            //    SQ_LDS_BANK_CONFLICT = 0, profiles/r02_cfg1_vec_pmc_summary.txt) + a register select.  1.7 % SLOWER per layer
+            //    (12 more VGPRs live per chunk, 6 selects, 3x the LDS bytes) - kept selectable as evidence, not shipped.
             const char *b16 = st + (((c * 2 + (q & 1)) ^ sw16) * 16);
             if (R16VEC) {
                 const f32x4 xv = *reinterpret_cast<const f32x4 *>(b16 + x16_row);
@@ -409,8 +414,10 @@ int launch_panel_v(const GemmArgs &a, hipStream_t stream);
 template <int T32, bool HALF, int EPI, int AMODE>
 int launch_panel(const GemmArgs &a, hipStream_t stream)
 {
-    static const bool scalar = [] { const char *e = getenv("LDIT_PANEL_R16"); return e && e[0] == 's'; }();
-    return scalar ? launch_panel_v<T32, HALF, EPI, AMODE, false>(a, stream) : launch_panel_v<T32, HALF, EPI, AMODE, true>(a, stream);
+    // LDIT_PANEL_R16=vec selects the conflict-free b128 remainder reads (see load_frags); the default scalar reads measured
+    // 1.7 % faster (profiles/README.md, round 2: three interleaved A/B pairs on one device)
+    static const bool vec = [] { const char *e = getenv("LDIT_PANEL_R16"); return e && e[0] == 'v'; }();
+    return vec ? launch_panel_v<T32, HALF, EPI, AMODE, true>(a, stream) : launch_panel_v<T32, HALF, EPI, AMODE, false>(a, stream);
 }
 
 template <int T32, bool HALF, int EPI, int AMODE, bool R16VEC>
