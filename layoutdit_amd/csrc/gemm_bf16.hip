@@ -534,12 +534,25 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
     double c128 = (double)((t128 + 255) / 256) * (r128[EPI] + 7.6e-3 * Ks);
     if (c128 < 5.0 + 11.4e-3 * Ks) c128 = 5.0 + 11.4e-3 * Ks;
     int pick = c256 <= c128 ? 3 : 2;
+    // Round 2: 192- and 320-row variants of the 8-wave tile against ROUND QUANTISATION - a launch is whole rounds of 256
+    // workgroups, and M = 64 x 197 rows makes 150 / 450 / 600 tiles of 256 x 256 for N = 768 / 2304 / 3072 (0.59 / 1.76 / 2.34
+    // rounds).  192 x 256 gives 198 tiles for N = 768 (one round, 77 % of the CUs busy instead of 59 %, each with 3/4 of
+    // the work); 320 x 256 gives 480 tiles for N = 3072 (2 rounds of 1.25 instead of 3 of 1.0).  Same kernel, same k-order
+    // per output element (bit-identical results), priced as rounds x tile height.
+    double best = c256 <= c128 ? c256 : c128;
+    const double per256 = a256[EPI] + 19.5e-3 * Ks;
+    for (int bm : {192, 320}) {
+        const long t = sp * ((a.M + bm - 1) / bm) * ((a.N + 255) / 256);
+        const double c = (double)((t + 255) / 256) * per256 * (bm / 256.0) * 1.03;      // 3 % handicap: prefer the fitted tiles on ties
+        if (c < best) { best = c; pick = bm == 192 ? 4 : 5; }
+    }
     if (const char *force = getenv("LDIT_GEMM_BF16_TILE")) {
-        if (force[0] >= '1' && force[0] <= '3' && force[1] == 0) pick = force[0] - '0';
+        if (force[0] >= '2' && force[0] <= '5' && force[1] == 0) pick = force[0] - '0';
     }
     switch (pick) {
         case 3: return launch_h<2, 4, 4, 2, EPI>(a, stream);     // 256 x 256, 8 waves (2 per SIMD)
-        case 1: return launch_h<2, 2, 4, 2, EPI>(a, stream);     // 256 x 128, 4 waves
+        case 4: return launch_h<2, 4, 3, 2, EPI>(a, stream);     // 192 x 256
+        case 5: return launch_h<2, 4, 5, 2, EPI>(a, stream);     // 320 x 256
         default: return launch_h<2, 2, 2, 2, EPI>(a, stream);    // 128 x 128, 4 waves
     }
 }

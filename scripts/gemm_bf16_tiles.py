@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""A/B of the bf16 GEMM tilings on the layer shapes of the bench configs, interleaved rounds in ONE process
+(LDIT_GEMM_BF16_TILE is read at every launch): 2 = 128x128, 3 = 256x256, 4 = 192x256, 5 = 320x256, auto = the picker."""
+import os, sys, statistics
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from layoutdit_amd import _lib, ops  # noqa: E402
+
+def shapes(M, C):
+    F = 4 * C
+    return [("qkv", M, 3 * C, C, _lib.EPI_BIAS), ("o_proj", M, C, C, _lib.EPI_SCALE_RESID), ("fc1", M, F, C, _lib.EPI_BIAS_GELU),
+            ("fc2", M, C, F, _lib.EPI_SCALE_RESID)]
+
+for M, C in ((64 * 197, 768), (32 * 197, 768), (16 * 1025, 1024)):
+    for name, m, n, k, epi in shapes(M, C):
+        x = torch.randn(m, k, device="cuda").to(torch.bfloat16); w = (torch.randn(n, k, device="cuda") * 0.05).to(torch.bfloat16)
+        b = torch.randn(n, device="cuda"); lam = torch.rand(n, device="cuda"); r = torch.randn(m, n, device="cuda")
+        kw = dict(epilogue=epi)
+        if epi == _lib.EPI_SCALE_RESID:
+            kw.update(lam=lam, residual=r, out=r)
+        res = {t: [] for t in ("2", "3", "4", "5", "auto")}
+        for rnd in range(5):
+            for t in res:
+                if t == "auto": os.environ.pop("LDIT_GEMM_BF16_TILE", None)
+                else: os.environ["LDIT_GEMM_BF16_TILE"] = t
+                for _ in range(3): ops.linear_bf16(x, w, b, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20): ops.linear_bf16(x, w, b, **kw)
+                e1.record(); torch.cuda.synchronize()
+                res[t].append(e0.elapsed_time(e1) / 20 * 1e3)
+        os.environ.pop("LDIT_GEMM_BF16_TILE", None)
+        med = {t: statistics.median(v) for t, v in res.items()}
+        fl = 2.0 * m * n * k
+        print(f"M={m:6d} {name:7s} N={n:5d} K={k:5d}  " + "  ".join(f"{t}:{med[t]:7.1f}us" for t in res) +
+              f"   best {fl / min(med.values()) / 1e6:7.1f} TF/s", flush=True)
