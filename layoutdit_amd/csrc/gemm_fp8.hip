@@ -426,8 +426,22 @@ int launch_q_tiled(const GemmArgs8 &a, hipStream_t stream)
     double c128 = (double)((t128 + 255) / 256) * (r128[EPI] + 4.25e-3 * a.K);
     if (c128 < 5.3 + 8e-3 * a.K) c128 = 5.3 + 8e-3 * a.K;
     int pick = c256 <= c128 ? 0 : 2;
+    // Round 2: 192- and 320-row variants of the 8-wave tile against round quantisation (see gemm_bf16.hip launch_h_tiled)
+    double best = c256 <= c128 ? c256 : c128;
+    const double per256 = a256[EPI] + 11.3e-3 * a.K;
+    for (int bm : {192, 320}) {
+        if (bm == 320 && EPI == EPI_SCALE_RESID) continue;      // its residual epilogue does not fit 256 VGPRs (spills)
+        const long t = (long)((a.M + bm - 1) / bm) * ((a.N + 255) / 256);
+        const double c = (double)((t + 255) / 256) * per256 * (bm / 256.0) * 1.03;
+        if (c < best) { best = c; pick = bm == 192 ? 3 : 4; }
+    }
     if (const char *force = getenv("LDIT_GEMM_FP8_TILE"))
-        if (force[0] >= '0' && force[0] <= '2' && force[1] == 0) pick = force[0] - '0';
+        if (force[0] >= '0' && force[0] <= '4' && force[1] == 0) pick = force[0] - '0';
+    if (k16 && pick > 2) pick = 0;
+    if (pick == 3) return launch_q<2, 4, 3, 2, EPI, true>(a, stream);      // 192 x 256
+    if (pick == 4 && EPI == EPI_SCALE_RESID) pick = 0;
+    if constexpr (EPI != EPI_SCALE_RESID)
+        if (pick == 4) return launch_q<2, 4, 5, 2, EPI, true>(a, stream);  // 320 x 256
     if (k16) {
         if (pick == 0) return launch_q<2, 4, 4, 2, EPI, false>(a, stream);
         if (pick == 1) return launch_q<2, 2, 4, 2, EPI, false>(a, stream);
