@@ -266,17 +266,15 @@ int ldit_conv3x3_nhwc_f32(const void *x, const void *w, const void *bias, void *
 size_t ldit_flat_param_bytes(const ldit_cfg *cfg);
 int ldit_flat_param_layout(const ldit_cfg *cfg, int64_t *offsets, int32_t n);
 
-/* bytes of: the activations kept between forward and backward / the backward's scratch / the transposed bf16 weights */
+/* bytes of: the activations kept between forward and backward / the backward's scratch */
 size_t ldit_train_saved_bytes(const ldit_cfg *cfg, int32_t batch);
 size_t ldit_train_workspace_bytes(const ldit_cfg *cfg, int32_t batch);
-size_t ldit_train_wt_bytes(const ldit_cfg *cfg);
 
-/* flat fp32 parameters -> bf16 copies of the four matrices per layer at their offsets of the bf16 packed block (the
- * forward's and the wgrad's operand layout; the fp32 vectors of that block are NOT filled: the train-step entry points
- * read them from the flat block) + their transposed bf16 copies for the dgrad GEMMs.  One read of every matrix.
- * Call after every optimizer step. */
-int ldit_pack_train(const ldit_cfg *cfg, const void *flat_params, void *packed, size_t packed_bytes, void *wT, size_t wt_bytes,
-                    ldit_stream stream);
+/* flat fp32 parameters -> bf16 copies of the four matrices per layer at their offsets of the bf16 packed block, in
+ * nn.Linear's own [out, in] layout: the forward reads them K-contiguous, the dgrad GEMMs read the SAME copy reduction-major
+ * through transposing LDS reads (no transposed copy exists), the wgrad GEMMs need no weight.  The fp32 vectors of the
+ * block are NOT filled: the train-step entry points read them from the flat block.  Call after every optimizer step. */
+int ldit_pack_train(const ldit_cfg *cfg, const void *flat_params, void *packed, size_t packed_bytes, ldit_stream stream);
 
 /* Training forward: as ldit_vit_forward, and keeps in `saved` what the backward needs (LayerNorm inputs and outputs, q|k|v,
  * the attention output and its log-sum-exp, the pre-LayerScale branch outputs, the MLP hidden after GELU and the GELU derivative at its pre-activation).
@@ -293,7 +291,7 @@ int ldit_vit_forward_train(const ldit_cfg *cfg, const void *packed, const void *
  * `workspace` between calls.  dtaps[i] (device fp32 [batch, 1+P, C] or NULL) = gradient of the loss with respect to hidden
  * state cfg->taps[i].  grads: flat fp32 block, OVERWRITTEN (not accumulated) for every parameter of the stages processed.
  * drop_scales: the pointer given to the forward (NULL there = NULL here).  x: the forward's input (patch-embedding wgrad). */
-int ldit_vit_backward(const ldit_cfg *cfg, const void *flat_params, const void *wT, const void *x, int32_t batch, void *const *dtaps,
+int ldit_vit_backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, const void *x, int32_t batch, void *const *dtaps,
                       const void *drop_scales, const void *saved, size_t saved_bytes, void *grads, size_t grads_bytes,
                       void *workspace, size_t workspace_bytes, int32_t stage_hi, int32_t stage_lo, ldit_stream stream,
                       double *ms, int64_t *launches);
@@ -325,6 +323,14 @@ int ldit_linear_bf16_ex(const void *X, int64_t lda, const void *W, const void *b
                         int64_t K, int32_t epilogue, const void *lam, const void *R, void *Y2, void *Ypre, const void *rowscale,
                         const void *aux, int64_t ldaux, int32_t splits, ldit_stream stream);
 int ldit_reduce_slabs_f32(const void *slabs, void *out, int64_t n, int32_t count, ldit_stream stream);
+/* The backward's two GEMM forms on reduction-major operands (gemm_bf16_tr.hip; operands gathered by ds_read_b64_tr_b16):
+ *   a_reduction_major = 0 (dgrad): Y[M,N] = epi( A[M,K] . W[K,N] ), A K-contiguous (K % 64 == 0), W row stride ldw;
+ *                                  epilogues LDIT_EPI_F32, LDIT_EPI_BIAS (bf16 out), LDIT_EPI_GELU_BWD (x aux, stride N)
+ *   a_reduction_major = 1 (wgrad): Y[M,N] = A[K,M]^T . W[K,N], any K (rows past K read zeros), fp32 out, optional split-K
+ * zeros: >= 128 bytes of device zeros.  M, N, lda, ldw multiples of 8. */
+int ldit_linear_bf16_tr(const void *A, int64_t lda, int32_t a_reduction_major, const void *W, int64_t ldw, void *Y, int64_t ldy,
+                        int64_t M, int64_t N, int64_t K, int32_t epilogue, const void *aux, int32_t splits, const void *zeros,
+                        ldit_stream stream);
 
 #ifdef __cplusplus
 }

@@ -78,8 +78,7 @@ SIGNATURES = {
     "ldit_flat_param_layout": (C.c_int, [C.POINTER(LditCfg), C.POINTER(_i64), _i32]),
     "ldit_train_saved_bytes": (_sz, [C.POINTER(LditCfg), _i32]),
     "ldit_train_workspace_bytes": (_sz, [C.POINTER(LditCfg), _i32]),
-    "ldit_train_wt_bytes": (_sz, [C.POINTER(LditCfg)]),
-    "ldit_pack_train": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _sz, _vp, _sz, _vp]),
+    "ldit_pack_train": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _sz, _vp]),
     "ldit_vit_forward_train": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _vp, _i32, C.POINTER(_vp), _vp, _vp, _sz, _vp,
                                          C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ldit_vit_backward": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _vp, _i32, C.POINTER(_vp), _vp, _vp, _sz, _vp, _sz, _vp, _sz,
@@ -93,6 +92,7 @@ SIGNATURES = {
     "ldit_linear_bf16_ex": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                                       _i32, _vp]),
     "ldit_reduce_slabs_f32": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "ldit_linear_bf16_tr": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _i32, _vp, _vp]),
 }
 
 _lib = None

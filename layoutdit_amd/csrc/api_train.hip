@@ -11,10 +11,11 @@
 // key bias, TF:306), wo, bo, lam1, ln2_w, ln2_b, w1, b1, w2, b2, lam2.  ldit_flat_param_layout reports the offsets; the
 // PyTorch mirror makes its nn.Parameters views of that block (layoutdit_amd/training.py).
 //
-// Backward of one layer = 8 GEMMs on the forward's K-contiguous MFMA kernel (2x the forward's FLOPs):
-//   dgrad  dX[M,K] = dY[M,N] . W[N,K]      -> X' = dY, W' = W^T   (bf16 transposed weight copies, made by ldit_pack_train)
-//   wgrad  dW[N,K] = dY^T[N,M] . X[M,K]    -> X' = dY^T, W' = X^T (64 x 64-tile transposes, rows padded to 64 with zeros;
-//                                             K = B*N tokens is split over workgroups, fp32 slabs summed in fixed order)
+// Backward of one layer = 8 MFMA GEMMs (2x the forward's FLOPs) on gemm_bf16_tr.hip, which reads reduction-major operands
+// through transposing LDS reads - nothing is transposed in memory:
+//   dgrad  dX[M,K] = dY[M,N] . W[N,K]      A = dY (K-contiguous), B = W exactly as nn.Linear stores it ([reduction N][K])
+//   wgrad  dW[N,K] = dY^T . X              both operands [reduction = tokens][outputs], as the forward / the dgrad left them;
+//                                          K = B*N tokens is split over workgroups, fp32 slabs summed in a fixed order
 // plus attention backward (attention_bwd_bf16.hip), LayerScale / LayerNorm backward with two-stage column reductions
 // (train_ops.hip).  Nothing uses atomics: gradients are bit-reproducible.
 #include "api_internal.h"
@@ -74,9 +75,9 @@ int pick_splits(int Mout, int Nout, int nk)
 }
 
 struct TrainWs {
-    size_t dh, dy, dz, dzT, da1, da1T, actT, dob, dqkv, dqkvT;
+    size_t zeros, dh, dy, dz, da1, dob, dqkv, patches;
     size_t slab[4];                 // wgrad slabs: w2 / patch_w, w1, wo, wqkv
-    size_t part[10];                // partial column sums, see layer_backward
+    size_t part[10];                // partial column sums, see backward()
     size_t part_rows_tile, part_rows_ln;
     size_t total;
 };
@@ -85,19 +86,16 @@ TrainWs train_ws_map(const Geo &g, int batch)
 {
     TrainWs w;
     const size_t M = (size_t)batch * g.T, C = g.C, F = g.F, Mp = pad64((int)M);
-    const size_t wide = std::max(std::max(F, 3 * C), (size_t)g.Kp);
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += up(bytes, 256); return at; };
+    w.zeros = take(256);                                  // zero page: reduction rows past the last token
     w.dh = take(M * C * 4);
     w.dy = take(M * C * 4);
     w.dz = take(M * C * 2);
-    w.dzT = take(C * Mp * 2);
     w.da1 = take(M * F * 2);
-    w.da1T = take(F * Mp * 2);
-    w.actT = take(wide * Mp * 2);
     w.dob = take(M * C * 2);
     w.dqkv = take(M * 3 * C * 2);
-    w.dqkvT = take(3 * C * Mp * 2);
+    w.patches = take((size_t)batch * g.P * g.Kp * 2);     // im2col of the batch, bf16 (patch-embedding wgrad)
     const size_t S = MAX_SPLITS;
     w.slab[0] = take(S * std::max(C * F, C * (size_t)g.Kp) * 4);
     w.slab[1] = take(S * F * C * 4);
@@ -110,26 +108,6 @@ TrainWs train_ws_map(const Geo &g, int batch)
     for (int i = 0; i < 10; ++i) w.part[i] = take((ln[i] ? w.part_rows_ln : w.part_rows_tile) * widths[i] * 4);
     w.total = o;
     return w;
-}
-
-struct WtLayer { size_t wqkvT, woT, w1T, w2T; };
-struct WtMap { std::vector<WtLayer> layer; size_t total; };
-
-WtMap wt_map(const Geo &g)
-{
-    WtMap m;
-    const size_t C = g.C, F = g.F;
-    size_t o = 0;
-    auto take = [&](size_t bytes) { size_t at = o; o += up(bytes, 256); return at; };
-    m.layer.resize(g.L);
-    for (int l = 0; l < g.L; ++l) {
-        m.layer[l].wqkvT = take(C * 3 * C * 2);       // [C][3C]
-        m.layer[l].woT = take(C * C * 2);             // [C][C]
-        m.layer[l].w1T = take(C * F * 2);             // [C][F]
-        m.layer[l].w2T = take(F * C * 2);             // [F][C]
-    }
-    m.total = o;
-    return m;
 }
 
 int train_geometry(const ldit_cfg *cfg, Geo &g)
@@ -225,28 +203,41 @@ int forward_train(const ldit_cfg *cfg, const void *packed, const void *flat_para
     return LDIT_OK;
 }
 
-// gradient of one wgrad GEMM:  out[Mout, Nout] = XT[Mout, Mp] . WT[Nout, Mp]^T  via split-K slabs (+ one reduce job)
-int wgrad(Probe &probe, ReduceJobs &jobs, const void *XT, const void *WT, float *out, float *slab, int Mout, int Nout, int Mp,
-          hipStream_t stream)
+// one wgrad:  out[Nout, Kout] = dY[tokens, Nout]^T . X[tokens, Kout], both operands as they lie in memory; split-K slabs
+int wgrad(Probe &probe, ReduceJobs &jobs, const void *dY, int ld_dy, const void *X, int ld_x, float *out, float *slab, int Nout,
+          int Kout, int tokens, const void *zeros, hipStream_t stream)
 {
     GemmExtra x{};
-    x.splits = pick_splits(Mout, Nout, Mp / 64);
-    if (x.splits == 1) return gemm(probe, XT, Mp, WT, nullptr, out, Nout, Mout, Nout, Mp, EPI_F32, nullptr, nullptr, nullptr, x, stream);
-    LDIT_TRY(gemm(probe, XT, Mp, WT, nullptr, slab, Nout, Mout, Nout, Mp, EPI_F32, nullptr, nullptr, nullptr, x, stream));
-    if (jobs.full()) LDIT_RUN(probe, LDIT_K_OTHER, launch_reduce_jobs(jobs, stream));
-    jobs.add(slab, out, (int64_t)Mout * Nout, x.splits, (int64_t)Mout * Nout);
+    x.zeros = zeros;
+    x.splits = pick_splits(Nout, Kout, (tokens + 63) / 64);
+    float *dst = x.splits == 1 ? out : slab;
+    LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_tr(dY, ld_dy, true, X, ld_x, nullptr, dst, Kout, Nout, Kout, tokens, EPI_F32, x, stream));
+    if (x.splits > 1) {
+        if (jobs.full()) LDIT_RUN(probe, LDIT_K_OTHER, launch_reduce_jobs(jobs, stream));
+        jobs.add(slab, out, (int64_t)Nout * Kout, x.splits, (int64_t)Nout * Kout);
+    }
     return LDIT_OK;
 }
 
-int backward(const ldit_cfg *cfg, const void *flat_params, const void *wT, const void *x, int32_t batch, void *const *dtaps,
+// one dgrad:  dX[M, Kout] = epi( dY[M, Nred] . W[Nred, Kout] ), W the bf16 copy of the nn.Linear weight as stored
+int dgrad(Probe &probe, const void *dY, int Nred, const void *W, void *dX, int M, int Kout, int epi, const void *aux, const void *zeros,
+          hipStream_t stream)
+{
+    GemmExtra x{};
+    x.zeros = zeros; x.aux = aux; x.ldaux = Kout;
+    LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_tr(dY, Nred, false, W, Kout, nullptr, dX, Kout, M, Kout, Nred, epi, x, stream));
+    return LDIT_OK;
+}
+
+int backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, const void *x, int32_t batch, void *const *dtaps,
              const void *drop_scales, const void *saved, size_t saved_bytes, void *grads, size_t grads_bytes, void *workspace, size_t ws_bytes,
              int stage_hi, int stage_lo, hipStream_t stream, Probe &probe)
 {
     Geo g;
     LDIT_TRY(train_geometry(cfg, g));
     if (batch <= 0) return fail(LDIT_EINVAL, "batch %d must be positive", batch);
-    if (!flat_params || !wT || !x || !saved || !grads || !workspace) return fail(LDIT_EINVAL, "backward: null pointer");
-    if (!aligned16(flat_params) || !aligned16(wT) || !aligned16(x) || !aligned16(saved) || !aligned16(grads) || !aligned16(workspace))
+    if (!flat_params || !packed || !x || !saved || !grads || !workspace) return fail(LDIT_EINVAL, "backward: null pointer");
+    if (!aligned16(flat_params) || !aligned16(packed) || !aligned16(x) || !aligned16(saved) || !aligned16(grads) || !aligned16(workspace))
         return fail(LDIT_EINVAL, "backward: pointers must be 16-byte aligned");
     if (stage_hi > g.L || stage_lo < 0 || stage_lo > stage_hi) return fail(LDIT_EINVAL, "backward: stages [%d, %d] outside [0, %d]", stage_lo, stage_hi, g.L);
     const SavedMap sm = saved_map(g, batch);
@@ -255,11 +246,11 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *wT, const
     if (ws_bytes < wm.total) return fail(LDIT_EWORKSPACE, "workspace %zu bytes < required %zu", ws_bytes, wm.total);
     const PackedMap gm = packed_map(g, LDIT_F32), &pm = gm;      // vectors are read from the flat fp32 master
     if (grads_bytes < gm.total) return fail(LDIT_EWORKSPACE, "gradient block %zu bytes < required %zu", grads_bytes, gm.total);
-    const WtMap tm = wt_map(g);
+    const PackedMap wm16 = packed_map(g, cfg->dtype);        // bf16 copies of the matrices (ldit_pack_train)
     for (int i = 0; dtaps && i < cfg->n_taps; ++i)
         if (dtaps[i] && !aligned16(dtaps[i])) return fail(LDIT_EINVAL, "backward: dtaps[%d] misaligned", i);
 
-    const char *P = static_cast<const char *>(flat_params), *WT = static_cast<const char *>(wT), *S = static_cast<const char *>(saved);
+    const char *P = static_cast<const char *>(flat_params), *W16 = static_cast<const char *>(packed), *S = static_cast<const char *>(saved);
     char *G = static_cast<char *>(grads), *ws = static_cast<char *>(workspace);
     auto F32 = [&](size_t off) { return reinterpret_cast<const float *>(P + off); };
     auto GR = [&](size_t off) { return reinterpret_cast<float *>(G + off); };
@@ -267,8 +258,9 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *wT, const
     const int M = batch * g.T, C = g.C, F = g.F, Mp = pad64(M);
     const size_t act = (size_t)M * C;
     float *dh = reinterpret_cast<float *>(ws + wm.dh), *dy = reinterpret_cast<float *>(ws + wm.dy);
-    char *dz = ws + wm.dz, *dzT = ws + wm.dzT, *da1 = ws + wm.da1, *da1T = ws + wm.da1T, *actT = ws + wm.actT, *dob = ws + wm.dob,
-         *dqkv = ws + wm.dqkv, *dqkvT = ws + wm.dqkvT;
+    char *dz = ws + wm.dz, *da1 = ws + wm.da1, *dob = ws + wm.dob, *dqkv = ws + wm.dqkv;
+    const char *zeros = ws + wm.zeros;
+    LDIT_HIP_CHECK(hipMemsetAsync(ws + wm.zeros, 0, 256, stream));
     // stochastic depth: the forward left the per-row factors (expanded from drop_scales) in the saved block
     const float *rowscale = drop_scales ? reinterpret_cast<const float *>(S + sm.rowscale) : nullptr;
     const float scale = 1.0f / sqrtf((float)g.D);
@@ -283,32 +275,23 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *wT, const
                 LDIT_RUN(probe, LDIT_K_OTHER, launch_add_inplace(dh, static_cast<const float *>(dtaps[i]), act, stream));
         if (st == 0) break;
         const int l = st - 1;
-        const PackedLayer &pl = pm.layer[l], &gl = gm.layer[l];
+        const PackedLayer &pl = pm.layer[l], &gl = gm.layer[l], &wl = wm16.layer[l];
         const SavedLayer &sl = sm.layer[l];
-        const WtLayer &tl = tm.layer[l];
         const float *rs1 = rowscale ? rowscale + (size_t)(2 * l) * M : nullptr, *rs2 = rowscale ? rowscale + (size_t)(2 * l + 1) * M : nullptr;
-        GemmExtra none{};
 
         // ---- MLP branch:  h_out = h_mid + rs2 lam2 (.) (gelu(y2 W1^T + b1) W2^T + b2) --------------------------------
-        LDIT_RUN(probe, LDIT_K_OTHER, launch_resid_bwd(dh, S + sl.z2, F32(pl.lam2), rs2, dz, dzT, M, C, Mp, PART(0), PART(1), stream));
-        LDIT_RUN(probe, LDIT_K_OTHER, launch_transpose_bf16(S + sl.g, false, actT, M, F, F, Mp, 0, nullptr, stream));
-        LDIT_TRY(wgrad(probe, jobs, dzT, actT, GR(gl.w2), reinterpret_cast<float *>(ws + wm.slab[0]), C, F, Mp, stream));
-        {
-            GemmExtra xg{};
-            xg.aux = S + sl.a1; xg.ldaux = F;
-            LDIT_TRY(gemm(probe, dz, C, WT + tl.w2T, nullptr, da1, F, M, F, C, EPI_GELU_BWD, nullptr, nullptr, nullptr, xg, stream));
-        }
-        LDIT_RUN(probe, LDIT_K_OTHER, launch_transpose_bf16(da1, false, da1T, M, F, F, Mp, 0, PART(2), stream));
-        LDIT_RUN(probe, LDIT_K_OTHER, launch_transpose_bf16(S + sl.y2, false, actT, M, C, C, Mp, 0, nullptr, stream));
-        LDIT_TRY(wgrad(probe, jobs, da1T, actT, GR(gl.w1), reinterpret_cast<float *>(ws + wm.slab[1]), F, C, Mp, stream));
-        LDIT_TRY(gemm(probe, da1, F, WT + tl.w1T, nullptr, dy, C, M, C, F, EPI_F32, nullptr, nullptr, nullptr, none, stream));
+        LDIT_RUN(probe, LDIT_K_OTHER, launch_resid_bwd(dh, S + sl.z2, F32(pl.lam2), rs2, dz, nullptr, M, C, Mp, PART(0), PART(1), stream));
+        LDIT_TRY(wgrad(probe, jobs, dz, C, S + sl.g, F, GR(gl.w2), reinterpret_cast<float *>(ws + wm.slab[0]), C, F, M, zeros, stream));
+        LDIT_TRY(dgrad(probe, dz, C, W16 + wl.w2, da1, M, F, EPI_GELU_BWD, S + sl.a1, zeros, stream));          // da1 = (dz W2) (.) gelu'
+        LDIT_RUN(probe, LDIT_K_OTHER, launch_colsum_bf16(da1, M, F, F, PART(2), stream));
+        LDIT_TRY(wgrad(probe, jobs, da1, F, S + sl.y2, C, GR(gl.w1), reinterpret_cast<float *>(ws + wm.slab[1]), F, C, M, zeros, stream));
+        LDIT_TRY(dgrad(probe, da1, F, W16 + wl.w1, dy, M, C, EPI_F32, nullptr, zeros, stream));
         LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bwd(dy, reinterpret_cast<const float *>(S + sl.h_mid), F32(pl.ln2_w), dh, M, C,
                                                               cfg->ln_eps, PART(3), PART(4), stream));
         // ---- attention branch:  h_mid = h_in + rs1 lam1 (.) (attn(LN1(h_in)) Wo^T + bo) --------------------------------
-        LDIT_RUN(probe, LDIT_K_OTHER, launch_resid_bwd(dh, S + sl.z1, F32(pl.lam1), rs1, dz, dzT, M, C, Mp, PART(5), PART(6), stream));
-        LDIT_RUN(probe, LDIT_K_OTHER, launch_transpose_bf16(S + sl.o, false, actT, M, C, C, Mp, 0, nullptr, stream));
-        LDIT_TRY(wgrad(probe, jobs, dzT, actT, GR(gl.wo), reinterpret_cast<float *>(ws + wm.slab[2]), C, C, Mp, stream));
-        LDIT_TRY(gemm(probe, dz, C, WT + tl.woT, nullptr, dob, C, M, C, C, EPI_BIAS, nullptr, nullptr, nullptr, none, stream));
+        LDIT_RUN(probe, LDIT_K_OTHER, launch_resid_bwd(dh, S + sl.z1, F32(pl.lam1), rs1, dz, nullptr, M, C, Mp, PART(5), PART(6), stream));
+        LDIT_TRY(wgrad(probe, jobs, dz, C, S + sl.o, C, GR(gl.wo), reinterpret_cast<float *>(ws + wm.slab[2]), C, C, M, zeros, stream));
+        LDIT_TRY(dgrad(probe, dz, C, W16 + wl.wo, dob, M, C, EPI_BIAS, nullptr, zeros, stream));
         {
             const char *qkv = S + sl.qkv;
             LDIT_RUN(probe, LDIT_K_ATTENTION,
@@ -316,10 +299,9 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *wT, const
                                                reinterpret_cast<const float *>(S + sl.lse), dqkv, dqkv + 2 * (size_t)C,
                                                dqkv + 4 * (size_t)C, batch, g.T, g.H, g.D, 3 * C, C, C, 3 * C, scale, stream));
         }
-        LDIT_RUN(probe, LDIT_K_OTHER, launch_transpose_bf16(dqkv, false, dqkvT, M, 3 * C, 3 * C, Mp, 0, PART(7), stream));
-        LDIT_RUN(probe, LDIT_K_OTHER, launch_transpose_bf16(S + sl.y1, false, actT, M, C, C, Mp, 0, nullptr, stream));
-        LDIT_TRY(wgrad(probe, jobs, dqkvT, actT, GR(gl.wqkv), reinterpret_cast<float *>(ws + wm.slab[3]), 3 * C, C, Mp, stream));
-        LDIT_TRY(gemm(probe, dqkv, 3 * C, WT + tl.wqkvT, nullptr, dy, C, M, C, 3 * C, EPI_F32, nullptr, nullptr, nullptr, none, stream));
+        LDIT_RUN(probe, LDIT_K_OTHER, launch_colsum_bf16(dqkv, M, 3 * C, 3 * C, PART(7), stream));
+        LDIT_TRY(wgrad(probe, jobs, dqkv, 3 * C, S + sl.y1, C, GR(gl.wqkv), reinterpret_cast<float *>(ws + wm.slab[3]), 3 * C, C, M, zeros, stream));
+        LDIT_TRY(dgrad(probe, dqkv, 3 * C, W16 + wl.wqkv, dy, M, C, EPI_F32, nullptr, zeros, stream));
         LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bwd(dy, reinterpret_cast<const float *>(S + sl.h_in), F32(pl.ln1_w), dh, M, C,
                                                               cfg->ln_eps, PART(8), PART(9), stream));
         // ---- second stage of this layer's reductions: 4 wgrad slab sums (queued above) + 10 vectors, one launch ----------
@@ -340,12 +322,13 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *wT, const
     }
     if (stage_lo == 0) {
         // ---- embeddings: h0[b, 0] = cls + pos[0];  h0[b, 1 + i] = patch_i . Wp^T + bp + pos[1 + i]  (TF:81-90, 168-172) ------
-        const int Mq = batch * g.P, Mqp = pad64(Mq);
+        const int Mq = batch * g.P;
         LDIT_RUN(probe, LDIT_K_OTHER, launch_embed_bwd_small(dh, GR(gm.pos), GR(gm.cls), GR(gm.patch_b), batch, g.T, C, stream));
-        LDIT_RUN(probe, LDIT_K_OTHER, launch_transpose_bf16(dh, true, dzT, Mq, C, C, Mqp, g.P, nullptr, stream));
-        LDIT_RUN(probe, LDIT_K_OTHER, launch_patches_transposed(static_cast<const float *>(x), actT, batch, g.in_ch, cfg->img_h,
-                                                               cfg->img_w, g.p, Mqp, stream));
-        LDIT_TRY(wgrad(probe, jobs, dzT, actT, GR(gm.patch_w), reinterpret_cast<float *>(ws + wm.slab[0]), C, g.Kp, Mqp, stream));
+        LDIT_RUN(probe, LDIT_K_OTHER, launch_rows_to_bf16(dh, dz, Mq, C, g.P, stream));                  // dE: patch rows of dh0, bf16
+        LDIT_RUN(probe, LDIT_K_OTHER, launch_patches_rows(static_cast<const float *>(x), ws + wm.patches, batch, g.in_ch, cfg->img_h,
+                                                         cfg->img_w, g.p, stream));
+        LDIT_TRY(wgrad(probe, jobs, dz, C, ws + wm.patches, g.Kp, GR(gm.patch_w), reinterpret_cast<float *>(ws + wm.slab[0]), C, g.Kp, Mq,
+                       zeros, stream));
         LDIT_RUN(probe, LDIT_K_OTHER, launch_reduce_jobs(jobs, stream));
     }
     return LDIT_OK;
@@ -397,40 +380,29 @@ size_t ldit_train_workspace_bytes(const ldit_cfg *cfg, int32_t batch)
     return train_ws_map(g, batch).total;
 }
 
-size_t ldit_train_wt_bytes(const ldit_cfg *cfg)
-{
-    Geo g;
-    if (train_geometry(cfg, g) != LDIT_OK) return 0;
-    return wt_map(g).total;
-}
-
-int ldit_pack_train(const ldit_cfg *cfg, const void *flat_params, void *packed, size_t packed_bytes, void *wT, size_t wt_bytes,
-                    ldit_stream stream_)
+int ldit_pack_train(const ldit_cfg *cfg, const void *flat_params, void *packed, size_t packed_bytes, ldit_stream stream_)
 {
     Geo g;
     LDIT_TRY(train_geometry(cfg, g));
-    if (!flat_params || !packed || !wT) return fail(LDIT_EINVAL, "pack_train: null pointer");
-    if (!aligned16(flat_params) || !aligned16(packed) || !aligned16(wT)) return fail(LDIT_EINVAL, "pack_train: pointers must be 16-byte aligned");
+    if (!flat_params || !packed) return fail(LDIT_EINVAL, "pack_train: null pointer");
+    if (!aligned16(flat_params) || !aligned16(packed)) return fail(LDIT_EINVAL, "pack_train: pointers must be 16-byte aligned");
     const PackedMap fm = packed_map(g, LDIT_F32), pm = packed_map(g, cfg->dtype);
-    const WtMap tm = wt_map(g);
     if (packed_bytes < pm.total) return fail(LDIT_EWORKSPACE, "packed buffer %zu bytes < required %zu", packed_bytes, pm.total);
-    if (wt_bytes < tm.total) return fail(LDIT_EWORKSPACE, "transposed-weight buffer %zu bytes < required %zu", wt_bytes, tm.total);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const char *Fp = static_cast<const char *>(flat_params);
-    char *P = static_cast<char *>(packed), *T = static_cast<char *>(wT);
-    const int C = g.C, F = g.F;
-    // one pass per matrix: W [rows, cols] fp32 -> bf16 W (forward / wgrad operand layout) and bf16 W^T [cols][rows] (dgrad);
-    // the fp32 vectors are NOT copied: the train-step entry points read them from the flat block itself
-    auto mat = [&](size_t dst, size_t src, int rows, int cols, size_t dstT) -> int {
-        return launch_transpose_bf16(Fp + src, true, T + dstT, rows, cols, cols, rows, 0, nullptr, stream, P + dst);
+    char *P = static_cast<char *>(packed);
+    const size_t C = g.C, F = g.F;
+    // bf16 copies of the four matrices per layer, in nn.Linear's own [out, in] layout: the forward reads them K-contiguous,
+    // the dgrad reads the same copy reduction-major, the wgrad needs no weight at all.  fp32 vectors are not copied.
+    auto mat = [&](size_t dst, size_t src, size_t n) -> int {
+        return launch_cvt_bf16(reinterpret_cast<const float *>(Fp + src), P + dst, n, stream);
     };
     for (int l = 0; l < g.L; ++l) {
         const PackedLayer &d = pm.layer[l], &s = fm.layer[l];
-        const WtLayer &t = tm.layer[l];
-        LDIT_TRY(mat(d.wqkv, s.wqkv, 3 * C, C, t.wqkvT));
-        LDIT_TRY(mat(d.wo, s.wo, C, C, t.woT));
-        LDIT_TRY(mat(d.w1, s.w1, F, C, t.w1T));
-        LDIT_TRY(mat(d.w2, s.w2, C, F, t.w2T));
+        LDIT_TRY(mat(d.wqkv, s.wqkv, 3 * C * C));
+        LDIT_TRY(mat(d.wo, s.wo, C * C));
+        LDIT_TRY(mat(d.w1, s.w1, F * C));
+        LDIT_TRY(mat(d.w2, s.w2, C * F));
     }
     return LDIT_OK;
 }
@@ -447,14 +419,14 @@ int ldit_vit_forward_train(const ldit_cfg *cfg, const void *packed, const void *
     return rc != LDIT_OK ? rc : rc2;
 }
 
-int ldit_vit_backward(const ldit_cfg *cfg, const void *flat_params, const void *wT, const void *x, int32_t batch, void *const *dtaps,
+int ldit_vit_backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, const void *x, int32_t batch, void *const *dtaps,
                       const void *drop_scales, const void *saved, size_t saved_bytes, void *grads, size_t grads_bytes, void *workspace,
                       size_t workspace_bytes, int32_t stage_hi, int32_t stage_lo, ldit_stream stream, double *ms, int64_t *launches)
 {
     Probe probe;
     probe.on = ms && launches;
     probe.stream = static_cast<hipStream_t>(stream);
-    int rc = backward(cfg, flat_params, wT, x, batch, dtaps, drop_scales, saved, saved_bytes, grads, grads_bytes, workspace, workspace_bytes, stage_hi,
+    int rc = backward(cfg, flat_params, packed, x, batch, dtaps, drop_scales, saved, saved_bytes, grads, grads_bytes, workspace, workspace_bytes, stage_hi,
                       stage_lo, probe.stream, probe);
     int rc2 = probe.collect(ms, launches);
     return rc != LDIT_OK ? rc : rc2;
@@ -533,6 +505,28 @@ int ldit_linear_bf16_ex(const void *X, int64_t lda, const void *W, const void *b
     x.Ypre = Ypre; x.rowscale = static_cast<const float *>(rowscale); x.aux = aux; x.ldaux = (int)ldaux; x.splits = splits < 1 ? 1 : splits;
     return launch_gemm_bf16_ex(X, (int)lda, W, static_cast<const float *>(bias), Y, (int)ldy, (int)M, (int)N, (int)K, epi,
                                static_cast<const float *>(lam), static_cast<const float *>(R), static_cast<float *>(Y2), x,
+                               static_cast<hipStream_t>(stream));
+}
+
+int ldit_linear_bf16_tr(const void *A, int64_t lda, int32_t a_reduction_major, const void *W, int64_t ldw, void *Y, int64_t ldy,
+                        int64_t M, int64_t N, int64_t K, int32_t epilogue, const void *aux, int32_t splits, const void *zeros,
+                        ldit_stream stream)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return fail(LDIT_EINVAL, "linear_bf16_tr: empty problem");
+    if (M * ldy >= (1ll << 31) || K * (lda > ldw ? lda : ldw) >= (1ll << 31) || M * lda >= (1ll << 31))
+        return fail(LDIT_EUNSUPPORTED, "linear_bf16_tr: operand exceeds 2^31 elements");
+    if (ldy < N || ldw < N || lda < (a_reduction_major ? M : K)) return fail(LDIT_EINVAL, "linear_bf16_tr: bad leading dimension");
+    if (!Y || !aligned16(Y)) return fail(LDIT_EINVAL, "linear_bf16_tr: output null or misaligned");
+    int epi;
+    switch (epilogue) {
+        case LDIT_EPI_BIAS: epi = EPI_BIAS; break;
+        case LDIT_EPI_F32: epi = EPI_F32; break;
+        case LDIT_EPI_GELU_BWD: epi = EPI_GELU_BWD; break;
+        default: return fail(LDIT_EINVAL, "linear_bf16_tr: epilogue %d not available", epilogue);
+    }
+    GemmExtra x{};
+    x.aux = aux; x.ldaux = (int)N; x.splits = splits < 1 ? 1 : splits; x.zeros = zeros;
+    return launch_gemm_bf16_tr(A, (int)lda, a_reduction_major != 0, W, (int)ldw, nullptr, Y, (int)ldy, (int)M, (int)N, (int)K, epi, x,
                                static_cast<hipStream_t>(stream));
 }
 

@@ -1,0 +1,146 @@
+// Shared by gemm_bf16.hip (K-contiguous operands) and gemm_bf16_tr.hip (operands read through transposing LDS reads):
+// launch arguments and the direct (ragged-tile) epilogue of the swapped-operand bf16 GEMMs.
+#pragma once
+#include "ldit_common.h"
+#include "epilogue_rows.h"
+
+namespace ldit {
+namespace {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BKB = 64;            // bf16 per k-tile: one 128-B LDS row
+constexpr int ROWB = 128;
+
+__device__ __forceinline__ void glds16h(const void *gsrc, char *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+
+struct GemmArgsH {
+    const bf16_t *A;     // [M, K] bf16
+    const bf16_t *W;     // [N, K] bf16
+    void *Y;             // [M, N] bf16 (BIAS, BIAS_GELU) or fp32 (SCALE_RESID)
+    float *Y2;           // optional fp32 tap copy (SCALE_RESID)
+    const float *bias;   // [N] fp32 or null
+    const float *lam;    // [N] fp32
+    const float *R;      // [M, N] fp32, may alias Y
+    int M, N, K, lda, ldy;
+    int ldw;             // gemm_bf16_tr.hip only: row stride of the reduction-major W operand
+    int direct_epi;      // LDIT_GEMM_DIRECT_EPILOGUE=1: interior tiles stored straight from the accumulators (A/B experiments)
+    GemmExtra x;         // train-step operands (Ypre, rowscale, aux, split-K); defaults = inference
+};
+
+template <int EPI> constexpr bool f32_out() { return EPI == EPI_SCALE_RESID || EPI == EPI_F32; }
+
+// MODE 0: tile inside the matrix, 16-B / 8-B accesses unchecked; MODE 1: columns inside, rows past M skipped (the ragged
+// last row tile keeps its vector accesses - a lane owns a row, so the element-wise path does not coalesce and cost ~20 us);
+// MODE 2: element-wise with checks.
+template <int TM, int TN, int EPI, int MODE>
+__device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane)
+{
+    const int c32 = lane & 31, h = lane >> 5;
+    const bool dual = p.Y2 != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        f32x4 bias[4], lam[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = nw + j * 32 + 8 * g + 4 * h + e;
+                const bool ok = MODE != 2 || n < p.N;
+                bias[g][e] = (ok && p.bias) ? p.bias[n] : 0.0f;
+                lam[g][e] = (EPI == EPI_SCALE_RESID && ok) ? p.lam[n] : 0.0f;
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = mw + i * 32 + c32;
+            if (MODE != 0 && m >= p.M) continue;
+            f32x4 res[4];
+            if (EPI == EPI_SCALE_RESID) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nw + j * 32 + 8 * g + 4 * h;
+                    const unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
+                    if (MODE != 2) res[g] = *reinterpret_cast<const f32x4 *>(p.R + o);
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) res[g][e] = (n + e < p.N) ? p.R[o + e] : 0.0f;
+                }
+                asm volatile("" ::: "memory");
+            }
+            const float rs = (EPI == EPI_SCALE_RESID && p.x.rowscale) ? p.x.rowscale[m] : 1.0f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nw + j * 32 + 8 * g + 4 * h;
+                const unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bias[g][e];
+                if ((EPI == EPI_BIAS_GELU || EPI == EPI_SCALE_RESID) && p.x.Ypre) {
+                    // saved for the backward: the pre-LayerScale value, or the GELU derivative at the pre-activation
+                    f32x4 sv = v;
+                    if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float ge, gr;
+                            gelu_and_grad_lp(v[e], ge, gr);
+                            sv[e] = gr;
+                        }
+                    }
+                    bf16_t *yp = static_cast<bf16_t *>(p.x.Ypre);
+                    if (MODE != 2) {
+                        const bf16x4 pk = {(bf16_t)sv[0], (bf16_t)sv[1], (bf16_t)sv[2], (bf16_t)sv[3]};
+                        *reinterpret_cast<bf16x4 *>(yp + o) = pk;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) yp[o + e] = (bf16_t)sv[e];
+                    }
+                }
+                if (EPI == EPI_GELU_BWD) {
+                    const bf16_t *ax = static_cast<const bf16_t *>(p.x.aux) + ((unsigned)m * (unsigned)p.x.ldaux + (unsigned)n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= (MODE != 2 || n + e < p.N) ? (float)ax[e] : 0.0f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = v[e];
+                    if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
+                    if (EPI == EPI_SCALE_RESID) t = p.x.rowscale ? __builtin_fmaf(lam[g][e] * rs, t, res[g][e]) : __builtin_fmaf(lam[g][e], t, res[g][e]);
+                    v[e] = t;
+                }
+                if (f32_out<EPI>()) {
+                    float *y = static_cast<float *>(p.Y);
+                    if (MODE != 2) {
+                        *reinterpret_cast<f32x4 *>(y + o) = v;
+                        if (dual) *reinterpret_cast<f32x4 *>(p.Y2 + o) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) { y[o + e] = v[e]; if (dual) p.Y2[o + e] = v[e]; }
+                    }
+                } else {
+                    bf16_t *y = static_cast<bf16_t *>(p.Y);
+                    if (MODE != 2) {
+                        const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        *reinterpret_cast<bf16x4 *>(y + o) = pk;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) y[o + e] = (bf16_t)v[e];
+                    }
+                }
+            }
+            if (EPI == EPI_SCALE_RESID) asm volatile("" ::: "memory");
+        }
+    }
+}
+
+}  // namespace
+}  // namespace ldit

@@ -1,0 +1,261 @@
+// bf16 MFMA GEMM whose operands are stored REDUCTION-MAJOR - the two GEMMs of a backward pass, without transposed copies:
+//
+//   dgrad   dX[M, Kout] = dY[M, Nred] . W[Nred, Kout]        A = dY  K-contiguous (as the forward's operands),
+//                                                            B = W as nn.Linear stores it: [reduction rows][output cols]
+//   wgrad   dW[Nout, Kout] = dY[tokens, Nout]^T . X[tokens, Kout]     BOTH operands [reduction rows = tokens][output cols]
+//
+// gemm_bf16.hip wants 8 consecutive reduction elements of one output row / column per lane (one ds_read_b128 of a
+// K-contiguous LDS row).  Here a reduction-major operand is staged as it lies in memory - LDS image [64 reduction rows]
+// [BT output columns], filled by LDS-DMA in whole 256 / 512-byte rows - and the MFMA fragment is gathered by
+// ds_read_b64_tr_b16, gfx950's transposing LDS read (4 reduction rows x 16 columns per 16-lane group, two reads per
+// 8-deep fragment, natural k order so it pairs with a K-contiguous operand on the other side).  The 64-byte granule of a
+// row is XOR-swizzled with (reduction row & 3) - on the DMA source address and on the read - so the four rows a group
+// touches fall on four different quarters of the 256-byte bank window (conflict-free; unswizzled they alias 4-way because
+// the row stride is a multiple of 256 bytes).
+// Reduction rows past the end (tokens are not a multiple of 64) are fetched from a page of zeros: LDS-DMA has no predication.
+//
+// Deliberately simple main loop (two LDS stages, one barrier per 64-deep k-tile, fragments of step s+1 read under the MFMAs
+// of step s, two waves per SIMD to cover each other): these GEMMs have K = tokens (12 608) or outputs >= 768, the k-loop
+// is long and its fixed costs small.  Same swapped-operand accumulator layout and epilogues as gemm_bf16.hip
+// (fp32 / split-K slabs, bf16, dgrad x saved GELU derivative).
+#include <cstdlib>
+
+#include "gemm_bf16_common.h"
+
+namespace ldit {
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// TA: A operand reduction-major (wgrad) or K-contiguous (dgrad).  The W operand is always reduction-major.
+template <int WM, int WN, int TM, int TN, int EPI, bool TA>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(const GemmArgsH p0)
+{
+    GemmArgsH p = p0;
+    constexpr int NWAVES = WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NLD = (BM + BN) / (8 * NWAVES);
+    constexpr int A_BYTES = BM * ROWB, STAGE = (BM + BN) * ROWB;
+    static_assert((BM == 128 || BM == 256) && (BN == 128 || BN == 256), "reduction-major images need 256- or 512-byte rows");
+    static_assert((BM + BN) % (8 * NWAVES) == 0, "DMA pieces must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int c32 = lane & 31, h = lane >> 5;
+
+    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+    const int ntiles = nbm * nbn, nblocks = ntiles * p.x.splits;
+    int tile;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = nblocks >> 3, rr = nblocks & 7;
+        tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    int nk = (p.K + BKB - 1) / BKB, kbeg = 0;
+    if (EPI == EPI_F32 && p.x.splits > 1) {
+        const int split = tile / ntiles, per = (nk + p.x.splits - 1) / p.x.splits, kt0 = split * per;
+        tile -= split * ntiles;
+        nk = nk - kt0 < per ? nk - kt0 : per;
+        kbeg = kt0 * BKB;
+        p.Y = static_cast<float *>(p.Y) + (size_t)split * (size_t)p.M * (size_t)p.ldy;
+    }
+    const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+
+    // ---- DMA geometry of this lane's pieces (piece = wave + NWAVES u; 8 * piece < BM: A operand, else W) -----------------
+    unsigned src[NLD];      // element offset of the lane's 16-byte chunk at reduction row 0 / k = 0 of the tile
+    int krow[NLD];          // reduction row inside the k-tile (reduction-major pieces only)
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+        const int piece = wave + NWAVES * u;
+        if (!TA && 8 * piece < BM) {
+            const int row = 8 * piece + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+            int gm = m0 + row;
+            gm = gm < p.M ? gm : p.M - 1;
+            src[u] = (unsigned)gm * (unsigned)p.lda + c * 8;
+            krow[u] = 0;
+        } else {
+            const bool isA = 8 * piece < BM;
+            const int BT = isA ? BM : BN, cpr = BT / 8, pa = isA ? piece : piece - BM / 8;
+            const int kr = pa * (1024 / (BT * 2)) + lane / cpr, chunk = lane % cpr;
+            int col = (isA ? m0 : n0) + ((((chunk >> 2) ^ (kr & 3)) << 5) | ((chunk & 3) << 3));
+            const int ncols = isA ? p.M : p.N;
+            col = col + 8 <= ncols ? col : ncols - 8;         // columns past the matrix: duplicates, discarded by the epilogue
+            src[u] = (unsigned)kr * (unsigned)(isA ? p.lda : p.ldw) + (unsigned)col;
+            krow[u] = kr;
+        }
+    }
+    auto issue = [&](int stage, int k0) {                     // k0: first reduction index of the k-tile
+        char *base = smem + stage * STAGE;
+        const bool ragged = k0 + BKB > p.K;                   // block-uniform: only the last k-tile of the matrix
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int piece = wave + NWAVES * u;
+            const bf16_t *g;
+            if (!TA && 8 * piece < BM) {
+                g = p.A + (src[u] + (unsigned)k0);
+            } else {
+                const bool isA = 8 * piece < BM;
+                const bf16_t *opnd = isA ? p.A : p.W;
+                g = opnd + ((size_t)k0 * (size_t)(isA ? p.lda : p.ldw) + src[u]);
+                if (ragged && k0 + krow[u] >= p.K) g = static_cast<const bf16_t *>(p.x.zeros) + 8 * (lane & 7);
+            }
+            glds16h(g, base + piece * 1024);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // ---- fragment addressing --------------------------------------------------------------------------------------------
+    // K-contiguous A (dgrad): as gemm_bf16.hip.  Reduction-major image: lane (group g16 = lane>>4, i16 = lane&15) addresses
+    // reduction row 16 s + 8 h + 4 t + (i16 >> 2), columns cb + 16 (g16 & 1) + 4 (i16 & 3) .. +3 and receives column
+    // cb + (lane & 31) of reduction rows 16 s + 8 h + 4 t + 0..3.
+    const int g16 = lane >> 4, i16 = lane & 15, swz = (i16 >> 2) & 3;
+    const int sw = (c32 >> 1) & 7;
+    const int a_row = (wm * TM * 32 + c32) * ROWB;
+    unsigned ta_addr[TM], tw_addr[TN];
+    {
+        constexpr int BPRA = BM * 2, BPRW = BN * 2;
+        const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)smem);
+        const int inrow = (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            ta_addr[i] = lds0 + (8 * h + (i16 >> 2)) * BPRA + ((((wm * TM + i)) ^ swz) << 6) + inrow;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            tw_addr[j] = lds0 + A_BYTES + (8 * h + (i16 >> 2)) * BPRW + ((((wn * TN + j)) ^ swz) << 6) + inrow;
+    }
+    auto tr_frag = [&](unsigned addr, int bpr, int s) -> bf16x8 {
+        union { s16x4 v[2]; bf16x8 f; } u;
+        // two transposing reads: reduction rows 16 s + 8 h + {0..3} and + {4..7}
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u.v[0]) : "v"(addr + (unsigned)((16 * s) * bpr)));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u.v[1]) : "v"(addr + (unsigned)((16 * s + 4) * bpr)));
+        return u.f;
+    };
+    auto load_frags = [&](int stage, int s, bf16x8(&xa)[TM], bf16x8(&wb)[TN]) {
+        const unsigned so = (unsigned)(stage * STAGE);
+        if (TA) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xa[i] = tr_frag(ta_addr[i] + so, BM * 2, s);
+        } else {
+            const char *base = smem + stage * STAGE + ((s * 2 + h) ^ sw) * 16;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const bf16x8 *>(base + a_row + i * 32 * ROWB);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wb[j] = tr_frag(tw_addr[j] + so, BN * 2, s);
+    };
+    auto mfma_step = [&](const bf16x8(&xa)[TM], const bf16x8(&wb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+    };
+
+    bf16x8 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
+    issue(0, kbeg);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue(cur ^ 1, kbeg + (kt + 1) * BKB);          // lands while this k-tile is multiplied
+        load_frags(cur, 0, xa0, wb0);
+        // the transposing reads are asm (hipcc would guard the builtin against the in-flight LDS-DMA with vmcnt(0)): wait
+        // for them by hand, and pin the MFMAs behind the wait
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(cur, 1, xa1, wb1);
+        mfma_step(xa0, wb0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(cur, 2, xa0, wb0);
+        mfma_step(xa1, wb1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(cur, 3, xa1, wb1);
+        mfma_step(xa0, wb0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(xa1, wb1);
+        __syncthreads();            // own DMA of tile kt+1 landed (vmcnt 0), every wave done reading stage cur
+    }
+
+    const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
+    const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
+    if (cols_in && m0 + BM <= p.M) {
+        store_rows_via_lds<TM, TN, EPI, f32_out<EPI>() ? EPI_OUT_F32 : EPI_OUT_BF16>(
+            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, nullptr, p.ldy, mw, nw, lane, 1.0f, 1.0f, p.x);
+    } else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
+    else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
+}
+
+template <int WM, int WN, int TM, int TN, int EPI, bool TA>
+int launch_tr(const GemmArgsH &a, hipStream_t stream)
+{
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int lds = 2 * (BM + BN) * ROWB;
+    static_assert(lds >= WM * WN * EPI_WAVE_BYTES, "epilogue slabs must fit the stage memory");
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    auto kern = gemm_bf16_tr<WM, WN, TM, TN, EPI, TA>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles * a.x.splits), dim3(64 * WM * WN), lds, stream, a);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+template <int EPI, bool TA>
+int launch_tr_tiled(const GemmArgsH &a, hipStream_t stream)
+{
+    // 256 x 256 (8 waves) when that fills most of a round, else 128 x 128 (4 waves, two workgroups per CU)
+    const long t256 = (long)a.x.splits * ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    int pick = t256 >= 160 ? 3 : 2;
+    if (const char *force = getenv("LDIT_GEMM_BF16_TR_TILE"))
+        if ((force[0] == '2' || force[0] == '3') && force[1] == 0) pick = force[0] - '0';
+    if (pick == 3) return launch_tr<2, 4, 4, 2, EPI, TA>(a, stream);
+    return launch_tr<2, 2, 2, 2, EPI, TA>(a, stream);
+}
+
+}  // namespace
+
+// Y[M, N] = epi( A . W ) with W [K rows (reduction), N cols] row stride ldw, and A either K-contiguous [M, K] (a_reduction_major
+// = false; K % 64 == 0) or reduction-major [K rows, M cols] (true; any K, rows past K read x.zeros).  lda / ldw multiples of 8,
+// M (when reduction-major) and N multiples of 8.  Epilogues: EPI_F32 (+ split-K), EPI_BIAS, EPI_GELU_BWD.
+int launch_gemm_bf16_tr(const void *A, int lda, bool a_reduction_major, const void *W, int ldw, const float *bias, void *Y, int ldy,
+                        int M, int N, int K, int epi, const GemmExtra &x, hipStream_t stream)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return fail(LDIT_EINVAL, "gemm_bf16_tr: empty problem");
+    if (!A || !W || !Y || !x.zeros) return fail(LDIT_EINVAL, "gemm_bf16_tr: null operand (a zero page is required)");
+    if (!aligned16(A) || !aligned16(W) || !aligned16(x.zeros) || (lda & 7) || (ldw & 7) || (N & 7) || N < 8)
+        return fail(LDIT_EINVAL, "gemm_bf16_tr: operands must be 16-byte aligned, strides and N multiples of 8");
+    if (a_reduction_major ? ((M & 7) || M < 8) : (K % BKB != 0)) return fail(LDIT_EUNSUPPORTED, "gemm_bf16_tr: M %% 8 (reduction-major A) or K %% 64 (K-contiguous A) violated");
+    const int nk = (K + BKB - 1) / BKB;
+    if (x.splits < 1 || x.splits > nk || (x.splits > 1 && (epi != EPI_F32 || ((nk + x.splits - 1) / x.splits) * (x.splits - 1) >= nk)))
+        return fail(LDIT_EINVAL, "gemm_bf16_tr: bad K-split %d", x.splits);
+    GemmArgsH a{};
+    a.A = static_cast<const bf16_t *>(A); a.W = static_cast<const bf16_t *>(W); a.Y = Y; a.bias = bias;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldy = ldy; a.x = x;
+    if (a_reduction_major) {
+        if (epi != EPI_F32) return fail(LDIT_EINVAL, "gemm_bf16_tr: wgrad form has the fp32 epilogue only");
+        return launch_tr_tiled<EPI_F32, true>(a, stream);
+    }
+    switch (epi) {
+        case EPI_F32: return launch_tr_tiled<EPI_F32, false>(a, stream);
+        case EPI_BIAS: return launch_tr_tiled<EPI_BIAS, false>(a, stream);
+        case EPI_GELU_BWD:
+            if (!x.aux || (x.ldaux & 3)) return fail(LDIT_EINVAL, "gemm_bf16_tr: GELU-backward epilogue needs its factor operand");
+            return launch_tr_tiled<EPI_GELU_BWD, false>(a, stream);
+        default: return fail(LDIT_EINVAL, "gemm_bf16_tr: epilogue %d not available", epi);
+    }
+}
+
+}  // namespace ldit

@@ -121,6 +121,7 @@ struct GemmExtra {
     const void *aux = nullptr;         // bf16 [M,N], row stride ldaux: EPI_GELU_BWD multiplies the accumulator with it
     int ldaux = 0;
     int splits = 1;                    // EPI_F32: K split into `splits` slabs, slab s at (float*)Y + s * M * ldy
+    const void *zeros = nullptr;       // gemm_bf16_tr.hip: >= 128 bytes of device zeros (source of reduction rows past the end)
 };
 
 struct GemmArgs {
@@ -168,6 +169,8 @@ int launch_gemm_bf16(const void *A, int lda, const void *W, const float *bias, v
                      const float *lam, const float *R, float *Y2, hipStream_t stream);
 int launch_gemm_bf16_ex(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
                         const float *lam, const float *R, float *Y2, const GemmExtra &x, hipStream_t stream);
+int launch_gemm_bf16_tr(const void *A, int lda, bool a_reduction_major, const void *W, int ldw, const float *bias, void *Y, int ldy,
+                        int M, int N, int K, int epi, const GemmExtra &x, hipStream_t stream);
 int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream);
 // fp8: the per-tensor part of the accumulator's dequantisation is d_act[0] when d_act is non-null (device), else the host
 // value ab_scale; d_wrow (device, [N], optional) multiplies per-output-channel weight scales onto it; d_out (device, 1
@@ -210,7 +213,9 @@ int launch_attention_bwd_bf16(const void *Q, const void *K, const void *V, const
 int launch_transpose_bf16(const void *src, bool src_f32, void *dst, int M, int N, int ld_src, int Mp, int skip_tokens,
                           float *colsum_part, hipStream_t stream, void *rowmajor_copy = nullptr);
 int launch_resid_bwd(const float *dh, const void *z, const float *lam, const float *rowscale, void *dz, void *dzT, int M, int C,
-                     int Mp, float *dlam_part, float *db_part, hipStream_t stream);
+                     int Mp, float *dlam_part, float *db_part, hipStream_t stream);      // dzT may be null
+int launch_colsum_bf16(const void *src, int M, int N, int ld, float *part, hipStream_t stream);   // part[ceil(M/64)][N]
+int launch_rows_to_bf16(const float *src, void *dst, int M, int N, int skip_tokens, hipStream_t stream);
 int layernorm_bwd_blocks(int64_t rows);
 int launch_layernorm_bwd(const float *dy, const float *x, const float *g, float *dh, int64_t rows, int C, float eps,
                          float *dg_part, float *db_part, hipStream_t stream);
@@ -218,6 +223,7 @@ int launch_add_inplace(float *a, const float *b, size_t n, hipStream_t stream);
 int launch_expand_rowscale(const float *drop, float *rowscale, int B, int T, int nvec, hipStream_t stream);
 int launch_embed_bwd_small(const float *dh0, float *dpos, float *dcls, float *dpb, int B, int T, int C, hipStream_t stream);
 int launch_patches_transposed(const float *x, void *out, int B, int in_ch, int img_h, int img_w, int p, int Mp, hipStream_t stream);
+int launch_patches_rows(const float *x, void *out, int B, int in_ch, int img_h, int img_w, int p, hipStream_t stream);
 int launch_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1, float b2, float eps, float wd,
                  int step, float grad_scale, hipStream_t stream);
 

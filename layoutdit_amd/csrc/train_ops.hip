@@ -89,6 +89,34 @@ __global__ void __launch_bounds__(256) transpose_tile(const void *__restrict__ s
     }
 }
 
+// part[blockIdx.y][n] = sum over the 64 rows of the tile of src[m][n] (bf16 source, fp32 sums): first stage of a bias gradient
+__global__ void __launch_bounds__(256) colsum_tile(const bf16_t *__restrict__ src, int M, int N, int ld, float *__restrict__ part)
+{
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), r0 = blockIdx.y * 64 + (threadIdx.x >> 6) * 16;
+    float s = 0.0f;
+    if (n < N)
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r)
+            if (r0 + r < M) s += (float)src[(size_t)(r0 + r) * ld + n];
+    red[threadIdx.x >> 6][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && n < N)
+        part[(size_t)blockIdx.y * N + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// dst[m][n] = bf16(src[row(m)][n]), row(m) skipping the CLS rows of a [B, 1 + P, C] token tensor when skip = P (else plain)
+__global__ void __launch_bounds__(256) rows_to_bf16(const float *__restrict__ src, bf16_t *__restrict__ dst, int M, int N4, int skip)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)M * N4) return;
+    const int m = (int)(i / N4), c4 = (int)(i - (size_t)m * N4);
+    const size_t srow = skip ? (size_t)(m / skip) * (skip + 1) + 1 + (m % skip) : (size_t)m;
+    const f32x4 v = reinterpret_cast<const f32x4 *>(src + srow * (size_t)N4 * 4)[c4];
+    const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    reinterpret_cast<bf16x4 *>(dst + (size_t)m * N4 * 4)[c4] = o;
+}
+
 // ---- LayerScale + residual backward (TF:432-434, 440-442 differentiated) ---------------------------------------------
 // h_out = h_in + (lam (.) z) rs[row]  =>  dz = dh (.) lam rs (bf16, row-major AND transposed [C][Mp] for the wgrad),
 // partial sums  dlam_part[blk][c] = sum_rows dh z rs ,  db_part[blk][c] = sum_rows dz  (db = gradient of the bias inside z).
@@ -138,9 +166,11 @@ __global__ void __launch_bounds__(256) resid_bwd_tile(const float *__restrict__ 
         bf16x8 a, b;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { a[e] = (bf16_t)tile[rb + e][cn]; b[e] = (bf16_t)tile[rb + 8 + e][cn]; }
-        bf16_t *d = dzT + (size_t)(n0 + cn) * Mp + m0 + rb;
-        *reinterpret_cast<bf16x8 *>(d) = a;
-        *reinterpret_cast<bf16x8 *>(d + 8) = b;
+        if (dzT) {
+            bf16_t *d = dzT + (size_t)(n0 + cn) * Mp + m0 + rb;
+            *reinterpret_cast<bf16x8 *>(d) = a;
+            *reinterpret_cast<bf16x8 *>(d + 8) = b;
+        }
     }
     if (tid < 128) {
         const int cn = tid & 63;
@@ -339,6 +369,20 @@ __global__ void __launch_bounds__(256) patches_transposed(const float *__restric
     }
 }
 
+// im2col of the image batch rounded to bf16, ROW-major: out[m][k], m = (b, gy, gx), k = (ch, dy, dx) - the reduction-major W
+// operand of the patch-embedding wgrad.  One workgroup per (b, gy, ch): p image rows of img_w floats -> gw x (p*p) values.
+__global__ void __launch_bounds__(256) patches_rows(const float *__restrict__ x, bf16_t *__restrict__ out, int in_ch, int img_h,
+                                                    int img_w, int p, int gw, int gh, int Kp)
+{
+    const int ch = blockIdx.x % in_ch, gy = (blockIdx.x / in_ch) % gh, b = blockIdx.x / (in_ch * gh);
+    const float *src = x + (((size_t)b * in_ch + ch) * img_h + (size_t)gy * p) * img_w;
+    for (int i = threadIdx.x; i < p * img_w; i += 256) {
+        const int dy = i / img_w, xx = i - dy * img_w, gx = xx / p, dx = xx - gx * p;
+        const size_t m = ((size_t)b * gh + gy) * gw + gx;
+        out[m * Kp + (ch * p + dy) * p + dx] = (bf16_t)src[i];
+    }
+}
+
 __global__ void __launch_bounds__(256) zero_pad_columns(bf16_t *__restrict__ buf, int rows, int M, int Mp)
 {
     const int r = blockIdx.x, pad = Mp - M;
@@ -408,6 +452,23 @@ int launch_resid_bwd(const float *dh, const void *z, const float *lam, const flo
     return LDIT_OK;
 }
 
+int launch_colsum_bf16(const void *src, int M, int N, int ld, float *part, hipStream_t stream)
+{
+    if (M <= 0 || N <= 0 || !src || !part) return fail(LDIT_EINVAL, "colsum: bad argument");
+    LAUNCH_CHECKED(colsum_tile, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0, stream,
+                   static_cast<const bf16_t *>(src), M, N, ld, part);
+    return LDIT_OK;
+}
+
+int launch_rows_to_bf16(const float *src, void *dst, int M, int N, int skip_tokens, hipStream_t stream)
+{
+    if (M <= 0 || N <= 0 || (N & 3) || !src || !dst) return fail(LDIT_EINVAL, "rows_to_bf16: bad argument");
+    const size_t total = (size_t)M * (N / 4);
+    LAUNCH_CHECKED(rows_to_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, static_cast<bf16_t *>(dst), M, N / 4,
+                   skip_tokens);
+    return LDIT_OK;
+}
+
 int layernorm_bwd_blocks(int64_t rows) { return (int)(rows < 4 * 512 ? (rows + 3) / 4 : 512); }
 
 int launch_layernorm_bwd(const float *dy, const float *x, const float *g, float *dh, int64_t rows, int C, float eps,
@@ -473,6 +534,14 @@ int launch_patches_transposed(const float *x, void *out, int B, int in_ch, int i
     LAUNCH_CHECKED(patches_transposed, dim3((unsigned)(B * gh * in_ch)), dim3(256), 0, stream, x, static_cast<bf16_t *>(out), in_ch,
                    img_h, img_w, p, gw, gh, Mp);
     if (Mp > M) LAUNCH_CHECKED(zero_pad_columns, dim3((unsigned)(in_ch * p * p)), dim3(256), 0, stream, static_cast<bf16_t *>(out), in_ch * p * p, M, Mp);
+    return LDIT_OK;
+}
+
+int launch_patches_rows(const float *x, void *out, int B, int in_ch, int img_h, int img_w, int p, hipStream_t stream)
+{
+    const int gh = img_h / p, gw = img_w / p;
+    LAUNCH_CHECKED(patches_rows, dim3((unsigned)(B * gh * in_ch)), dim3(256), 0, stream, x, static_cast<bf16_t *>(out), in_ch, img_h,
+                   img_w, p, gw, gh, in_ch * p * p);
     return LDIT_OK;
 }
 

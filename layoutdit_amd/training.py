@@ -105,7 +105,6 @@ class FlatState:
                 p.data = view
         # scratch of the library, sized once per batch size
         self.packed = torch.empty(lib.ldit_packed_bytes(C.byref(self.lcfg)), dtype=torch.uint8, device=self.device)
-        self.wt = torch.empty(lib.ldit_train_wt_bytes(C.byref(self.lcfg)), dtype=torch.uint8, device=self.device)
         self._packed_version = None
         self._ws: Dict[int, torch.Tensor] = {}
 
@@ -131,13 +130,12 @@ class FlatState:
         return tuple(p._version for _, p, _, _ in self.named)
 
     def repack(self, force: bool = False) -> None:
-        """flat fp32 parameters -> bf16 operand copies (+ transposed copies for dgrad), when they changed."""
+        """flat fp32 parameters -> bf16 operand copies of the matrices, when they changed."""
         v = self.version()
         if force or v != self._packed_version:
             with torch.cuda.device(self.device):
                 _lib.check(_lib.load().ldit_pack_train(C.byref(self.lcfg), self.params.data_ptr(), self.packed.data_ptr(),
-                                                       self.packed.numel(), self.wt.data_ptr(), self.wt.numel(),
-                                                       torch.cuda.current_stream(self.device).cuda_stream))
+                                                       self.packed.numel(), torch.cuda.current_stream(self.device).cuda_stream))
             self._packed_version = v
 
     def workspace(self, batch: int) -> torch.Tensor:
@@ -182,7 +180,7 @@ class FlatState:
         ws = self.workspace(B)
         ms, cnt = self._probe(timing)
         with torch.cuda.device(self.device):
-            _lib.check(lib.ldit_vit_backward(C.byref(lcfg), self.params.data_ptr(), self.wt.data_ptr(), x.data_ptr(), B, ptrs,
+            _lib.check(lib.ldit_vit_backward(C.byref(lcfg), self.params.data_ptr(), self.packed.data_ptr(), x.data_ptr(), B, ptrs,
                                              None if drop_scales is None else drop_scales.data_ptr(), saved.data_ptr(),
                                              saved.numel(), self.grads.data_ptr(), self.grads.numel() * 4, ws.data_ptr(),
                                              ws.numel(), stage_hi, stage_lo,

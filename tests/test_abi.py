@@ -230,7 +230,7 @@ def test_train_step_layout_and_sizing_are_host_side():
     assert o[-1] == n_params + L * Cc                       # + the zero key-bias third per layer
     M = 64 * 197
     assert lib.ldit_train_saved_bytes(C.byref(lc), 64) >= L * M * (2 * 4 * Cc + 2 * (8 * Cc + 2 * F))
-    assert lib.ldit_train_workspace_bytes(C.byref(lc), 64) > 0 and lib.ldit_train_wt_bytes(C.byref(lc)) >= 2 * L * (4 * Cc * Cc + 2 * Cc * F)
+    assert lib.ldit_train_workspace_bytes(C.byref(lc), 64) > 0
     assert lib.ldit_train_saved_bytes(C.byref(lc32), 64) == 0 and "bf16" in lib.ldit_last_error().decode()      # fp32 build
     big = _cfg(cfgs.vit_large(), 512, 512)
     big.dtype = _lib.DTYPE_BF16

@@ -347,3 +347,41 @@ def test_train_mode_without_grad_applies_stochastic_depth(monkeypatch):
     m32 = DiTEncoder(cfg).load_numpy(w).to(DEV).train()
     with pytest.raises(NotImplementedError, match="bf16"):
         m32(torch.from_numpy(x).to(DEV))
+
+
+# ---- reduction-major GEMMs (dgrad / wgrad without transposed copies) --------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,epi", [(394, 768, 256, "f32"), (1040, 384, 192, "bf16"), (300, 200, 64, "gelu"), (12608, 768, 3072, "f32"),
+                                       (68, 512, 128, "gelu")])
+def test_dgrad_reads_the_weight_as_stored(M, N, K, epi):
+    """dX[M, N] = dY[M, K] . W[K, N] with W in nn.Linear's own [reduction, output] layout (ds_read_b64_tr_b16 gathers it)."""
+    lib = _lib.load()
+    dy, w = _bf(_rand(60, M, K, scale=0.5)), _bf(_rand(61, K, N, scale=0.05))
+    zeros = torch.zeros(64, device=DEV)
+    ref = dy.double() @ w.double()
+    code = {"f32": _lib.EPI_F32, "bf16": _lib.EPI_BIAS, "gelu": _lib.EPI_GELU_BWD}[epi]
+    out = torch.full((M, N), float("nan"), dtype=torch.float32 if epi == "f32" else BF, device=DEV)
+    aux = _bf(_rand(62, M, N, scale=0.5) + 0.5).to(DEV) if epi == "gelu" else None
+    dyd, wd = dy.to(DEV), w.to(DEV)
+    _lib.check(lib.ldit_linear_bf16_tr(dyd.data_ptr(), K, 0, wd.data_ptr(), N, out.data_ptr(), N, M, N, K, code,
+                                       None if aux is None else aux.data_ptr(), 1, zeros.data_ptr(), _stream()))
+    if aux is not None:
+        ref = ref * aux.cpu().double()
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < (1e-5 if epi == "f32" else 3e-3)
+
+
+@pytest.mark.parametrize("T,Nout,Kout,splits", [(12608, 768, 3072, 3), (68, 128, 512, 2), (197, 384, 128, 1), (1000, 256, 768, 8),
+                                               (12544, 768, 768, 8)])
+def test_wgrad_reads_both_operands_token_major(T, Nout, Kout, splits):
+    """dW[Nout, Kout] = dY[T, Nout]^T . X[T, Kout]: both operands reduction-major, tokens not a multiple of 64 (zero page),
+    K split over workgroups into slabs summed in a fixed order."""
+    lib = _lib.load()
+    dy, x = _bf(_rand(70, T, Nout, scale=0.3)), _bf(_rand(71, T, Kout, scale=0.3))
+    zeros = torch.zeros(64, device=DEV)
+    dyd, xd = dy.to(DEV), x.to(DEV)
+    slabs = torch.full((splits, Nout, Kout), float("nan"), device=DEV)
+    _lib.check(lib.ldit_linear_bf16_tr(dyd.data_ptr(), Nout, 1, xd.data_ptr(), Kout, slabs.data_ptr(), Kout, Nout, Kout, T, _lib.EPI_F32,
+                                       None, splits, zeros.data_ptr(), _stream()))
+    out = slabs[0] if splits == 1 else torch.empty((Nout, Kout), device=DEV)
+    if splits > 1:
+        _lib.check(lib.ldit_reduce_slabs_f32(slabs.data_ptr(), out.data_ptr(), Nout * Kout, splits, _stream()))
+    assert rel_l2(out.cpu().numpy(), (dy.double().T @ x.double()).numpy()) < 1e-5
