@@ -218,7 +218,7 @@ int launch_tr_tiled(const GemmArgsH &a, hipStream_t stream)
 {
     // 256 x 256 (8 waves) when that fills most of a round, else 128 x 128 (4 waves, two workgroups per CU)
     const long t256 = (long)a.x.splits * ((a.M + 255) / 256) * ((a.N + 255) / 256);
-    int pick = t256 >= 160 ? 3 : 2;
+    int pick = t256 >= 120 ? 3 : 2;
     if (const char *force = getenv("LDIT_GEMM_BF16_TR_TILE"))
         if ((force[0] == '2' || force[0] == '3') && force[1] == 0) pick = force[0] - '0';
     if (pick == 3) return launch_tr<2, 4, 4, 2, EPI, TA>(a, stream);

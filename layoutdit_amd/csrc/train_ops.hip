@@ -89,20 +89,32 @@ __global__ void __launch_bounds__(256) transpose_tile(const void *__restrict__ s
     }
 }
 
-// part[blockIdx.y][n] = sum over the 64 rows of the tile of src[m][n] (bf16 source, fp32 sums): first stage of a bias gradient
+// part[blockIdx.y][n] = sum over the 64 rows of the tile of src[m][n] (bf16 source, fp32 sums): first stage of a bias gradient.
+// Thread = 8 consecutive columns (one 16-byte load per row) x 16 rows; a workgroup covers 64 rows x 512 columns.
 __global__ void __launch_bounds__(256) colsum_tile(const bf16_t *__restrict__ src, int M, int N, int ld, float *__restrict__ part)
 {
-    __shared__ float red[4][64];
-    const int n = blockIdx.x * 64 + (threadIdx.x & 63), r0 = blockIdx.y * 64 + (threadIdx.x >> 6) * 16;
-    float s = 0.0f;
+    __shared__ float red[4][64][9];
+    const int cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 512 + cg * 8, r0 = blockIdx.y * 64 + rg * 16;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (n < N)
 #pragma unroll 4
         for (int r = 0; r < 16; ++r)
-            if (r0 + r < M) s += (float)src[(size_t)(r0 + r) * ld + n];
-    red[threadIdx.x >> 6][threadIdx.x & 63] = s;
+            if (r0 + r < M) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8 *>(src + (size_t)(r0 + r) * ld + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+            }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rg][cg][e] = s[e];
     __syncthreads();
-    if (threadIdx.x < 64 && n < N)
-        part[(size_t)blockIdx.y * N + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    // 512 columns, 256 threads: two columns each, fixed order over the four row groups
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int c = threadIdx.x * 2 + t, col = blockIdx.x * 512 + c;
+        if (col < N)
+            part[(size_t)blockIdx.y * N + col] = (red[0][c >> 3][c & 7] + red[1][c >> 3][c & 7]) + (red[2][c >> 3][c & 7] + red[3][c >> 3][c & 7]);
+    }
 }
 
 // dst[m][n] = bf16(src[row(m)][n]), row(m) skipping the CLS rows of a [B, 1 + P, C] token tensor when skip = P (else plain)
@@ -285,26 +297,31 @@ __global__ void __launch_bounds__(256) layernorm_bwd_rows(const float *__restric
 }
 
 // ---- second stage of the column reductions / split-K slab sums ---------------------------------------------------------
-// job j: out[n] = sum_{p < P} part[p * stride + n], n < N (fixed order).  grid.x = sum over jobs of ceil(N / 256).
+// job j: out[n] = sum_{p < P} part[p * stride + n], n < N (fixed order).  grid.x = sum over jobs of ceil(N / 1024).
 __global__ void __launch_bounds__(256) reduce_jobs_kernel(const ReduceJobs jobs)
 {
     int blk = blockIdx.x, j = 0;
     while (j + 1 < jobs.n && blk >= jobs.first_block[j + 1]) ++j;
     blk -= jobs.first_block[j];
-    const int64_t n = (int64_t)blk * 256 + threadIdx.x;
+    const int64_t n = ((int64_t)blk * 256 + threadIdx.x) * 4;      // four consecutive outputs per thread (16-byte accesses)
     if (n >= jobs.N[j]) return;
     const float *p = jobs.part[j] + n;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     const int64_t st = jobs.stride[j];
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
     int q = 0;
-    for (; q + 3 < jobs.P[j]; q += 4) {
-        s0 += p[(int64_t)q * st];
-        s1 += p[(int64_t)(q + 1) * st];
-        s2 += p[(int64_t)(q + 2) * st];
-        s3 += p[(int64_t)(q + 3) * st];
+    for (; q + 1 < jobs.P[j]; q += 2) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (int64_t)q * st), b = *reinterpret_cast<const f32x4 *>(p + (int64_t)(q + 1) * st);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s0[e] += a[e]; s1[e] += b[e]; }
     }
-    for (; q < jobs.P[j]; ++q) s0 += p[(int64_t)q * st];
-    jobs.out[j][n] = (s0 + s1) + (s2 + s3);
+    if (q < jobs.P[j]) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (int64_t)q * st);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s0[e] += a[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s0[e] += s1[e];
+    *reinterpret_cast<f32x4 *>(jobs.out[j] + n) = s0;
 }
 
 // ---- small element-wise helpers ------------------------------------------------------------------------------------------
@@ -455,7 +472,8 @@ int launch_resid_bwd(const float *dh, const void *z, const float *lam, const flo
 int launch_colsum_bf16(const void *src, int M, int N, int ld, float *part, hipStream_t stream)
 {
     if (M <= 0 || N <= 0 || !src || !part) return fail(LDIT_EINVAL, "colsum: bad argument");
-    LAUNCH_CHECKED(colsum_tile, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0, stream,
+    if ((N & 7) || (ld & 7) || (reinterpret_cast<uintptr_t>(src) & 15u)) return fail(LDIT_EINVAL, "colsum: N, ld multiples of 8, 16-byte aligned source");
+    LAUNCH_CHECKED(colsum_tile, dim3((unsigned)((N + 511) / 512), (unsigned)((M + 63) / 64)), dim3(256), 0, stream,
                    static_cast<const bf16_t *>(src), M, N, ld, part);
     return LDIT_OK;
 }
@@ -498,8 +516,10 @@ int launch_reduce_jobs(ReduceJobs &jobs, hipStream_t stream)
     if (jobs.n <= 0) return LDIT_OK;
     int blocks = 0;
     for (int j = 0; j < jobs.n; ++j) {
+        if ((jobs.N[j] & 3) || (jobs.stride[j] & 3) || (reinterpret_cast<uintptr_t>(jobs.part[j]) & 15u) || (reinterpret_cast<uintptr_t>(jobs.out[j]) & 15u))
+            return fail(LDIT_EINVAL, "reduce: lengths and strides must be multiples of 4 floats, pointers 16-byte aligned");
         jobs.first_block[j] = blocks;
-        blocks += (int)((jobs.N[j] + 255) / 256);
+        blocks += (int)((jobs.N[j] / 4 + 255) / 256);
     }
     LAUNCH_CHECKED(reduce_jobs_kernel, dim3(blocks), dim3(256), 0, stream, jobs);
     jobs.n = 0;
