@@ -307,20 +307,31 @@ __global__ void __launch_bounds__(256) reduce_jobs_kernel(const ReduceJobs jobs)
     if (n >= jobs.N[j]) return;
     const float *p = jobs.part[j] + n;
     const int64_t st = jobs.stride[j];
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    const int P = jobs.P[j];
     int q = 0;
-    for (; q + 1 < jobs.P[j]; q += 2) {
+    for (; q + 3 < P; q += 4) {            // four 16-byte loads in flight per thread
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (int64_t)q * st), b = *reinterpret_cast<const f32x4 *>(p + (int64_t)(q + 1) * st);
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(p + (int64_t)(q + 2) * st), d = *reinterpret_cast<const f32x4 *>(p + (int64_t)(q + 3) * st);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s0[e] += a[e]; s1[e] += b[e]; s2[e] += c[e]; s3[e] += d[e]; }
+    }
+    if (q + 2 < P) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (int64_t)q * st), b = *reinterpret_cast<const f32x4 *>(p + (int64_t)(q + 1) * st);
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(p + (int64_t)(q + 2) * st);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s0[e] += a[e]; s1[e] += b[e]; s2[e] += c[e]; }
+    } else if (q + 1 < P) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (int64_t)q * st), b = *reinterpret_cast<const f32x4 *>(p + (int64_t)(q + 1) * st);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s0[e] += a[e]; s1[e] += b[e]; }
-    }
-    if (q < jobs.P[j]) {
+    } else if (q < P) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (int64_t)q * st);
 #pragma unroll
         for (int e = 0; e < 4; ++e) s0[e] += a[e];
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s0[e] += s1[e];
+    for (int e = 0; e < 4; ++e) s0[e] = (s0[e] + s1[e]) + (s2[e] + s3[e]);
     *reinterpret_cast<f32x4 *>(jobs.out[j] + n) = s0;
 }
 
