@@ -270,11 +270,14 @@ int ldit_flat_param_layout(const ldit_cfg *cfg, int64_t *offsets, int32_t n);
 size_t ldit_train_saved_bytes(const ldit_cfg *cfg, int32_t batch);
 size_t ldit_train_workspace_bytes(const ldit_cfg *cfg, int32_t batch);
 
-/* flat fp32 parameters -> bf16 copies of the four matrices per layer at their offsets of the bf16 packed block, in
- * nn.Linear's own [out, in] layout: the forward reads them K-contiguous, the dgrad GEMMs read the SAME copy reduction-major
- * through transposing LDS reads (no transposed copy exists), the wgrad GEMMs need no weight.  The fp32 vectors of the
- * block are NOT filled: the train-step entry points read them from the flat block.  Call after every optimizer step. */
-int ldit_pack_train(const ldit_cfg *cfg, const void *flat_params, void *packed, size_t packed_bytes, ldit_stream stream);
+/* The bf16 MIRROR of the flat parameter block: element i = bf16(flat[i]), ldit_train_mirror_bytes(cfg) bytes.  It is the
+ * `packed` argument of the two train-step entry points below: the forward reads a matrix K-contiguous at half its fp32
+ * offset, the dgrad GEMMs read the SAME copy reduction-major through transposing LDS reads (no transposed copy exists),
+ * the wgrad GEMMs need no weight; fp32 vectors are read from the flat block itself.  ldit_pack_train rebuilds it from
+ * the flat block in one pass (after loading weights, or after a foreign optimizer changed them); ldit_adamw_step keeps it
+ * current by itself when handed the mirror. */
+size_t ldit_train_mirror_bytes(const ldit_cfg *cfg);
+int ldit_pack_train(const ldit_cfg *cfg, const void *flat_params, void *mirror, size_t mirror_bytes, ldit_stream stream);
 
 /* Training forward: as ldit_vit_forward, and keeps in `saved` what the backward needs (LayerNorm inputs and outputs, q|k|v,
  * the attention output and its log-sum-exp, the pre-LayerScale branch outputs, the MLP hidden after GELU and the GELU derivative at its pre-activation).
@@ -298,9 +301,11 @@ int ldit_vit_backward(const ldit_cfg *cfg, const void *flat_params, const void *
 
 /* Fused AdamW over n fp32 elements (torch.optim.AdamW semantics, decoupled weight decay), step counts from 1:
  *   g = grads * grad_scale ; p *= 1 - lr wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
- *   p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps).   n % 4 == 0, all pointers 16-byte aligned. */
+ *   p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps).   n % 4 == 0, all pointers 16-byte aligned.
+ * bf16_mirror (optional, n bf16 elements): receives bf16(p) of the updated parameters in the same pass. */
 int ldit_adamw_step(void *params, const void *grads, void *exp_avg, void *exp_avg_sq, int64_t n, float lr, float beta1,
-                    float beta2, float eps, float weight_decay, int32_t step, float grad_scale, ldit_stream stream);
+                    float beta2, float eps, float weight_decay, int32_t step, float grad_scale, void *bf16_mirror,
+                    ldit_stream stream);
 
 /* ---- the kernels of the backward, one entry point each (unit parity tests) ---- */
 /* ldit_attention_bf16 that also writes lse[b][h][q] = log2 sum_k exp2(scale log2(e) q.k)  (fp32 [B, H, N]) */

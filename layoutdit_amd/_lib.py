@@ -78,12 +78,13 @@ SIGNATURES = {
     "ldit_flat_param_layout": (C.c_int, [C.POINTER(LditCfg), C.POINTER(_i64), _i32]),
     "ldit_train_saved_bytes": (_sz, [C.POINTER(LditCfg), _i32]),
     "ldit_train_workspace_bytes": (_sz, [C.POINTER(LditCfg), _i32]),
+    "ldit_train_mirror_bytes": (_sz, [C.POINTER(LditCfg)]),
     "ldit_pack_train": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _sz, _vp]),
     "ldit_vit_forward_train": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _vp, _i32, C.POINTER(_vp), _vp, _vp, _sz, _vp,
                                          C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ldit_vit_backward": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _vp, _i32, C.POINTER(_vp), _vp, _vp, _sz, _vp, _sz, _vp, _sz,
                                     _i32, _i32, _vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
-    "ldit_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp]),
+    "ldit_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _vp]),
     "ldit_attention_fwd_lse_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ldit_attention_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                           _i64, _f32, _vp]),

@@ -149,8 +149,9 @@ int forward_train(const ldit_cfg *cfg, const void *packed, const void *flat_para
         return fail(LDIT_EUNSUPPORTED, "batch %d: activation index space exceeds 2^31 elements, split the batch", batch);
     const SavedMap sm = saved_map(g, batch);
     if (saved_bytes < sm.total) return fail(LDIT_EWORKSPACE, "saved-activation block %zu bytes < required %zu", saved_bytes, sm.total);
-    // matrices: bf16 copies in `packed`; every fp32 vector (and the fp32 patch projection): straight from the flat master
-    const PackedMap pmat = packed_map(g, cfg->dtype), pm = packed_map(g, LDIT_F32);
+    // `packed` is the bf16 MIRROR of the flat fp32 block (element i of the mirror = bf16 of element i of the master): a matrix
+    // sits at half its fp32 byte offset.  Every fp32 vector (and the fp32 patch projection) is read from the master itself.
+    const PackedMap pm = packed_map(g, LDIT_F32);
     const char *P = static_cast<const char *>(packed), *FP = static_cast<const char *>(flat_params);
     auto F32 = [&](size_t off) { return reinterpret_cast<const float *>(FP + off); };
     char *S = static_cast<char *>(saved);
@@ -180,7 +181,7 @@ int forward_train(const ldit_cfg *cfg, const void *packed, const void *flat_para
     }
     const float scale = 1.0f / sqrtf((float)g.D);
     for (int l = 0; l < g.L; ++l) {
-        const PackedLayer &pl = pm.layer[l], &ml = pmat.layer[l];
+        const PackedLayer &pl = pm.layer[l];
         const SavedLayer &sl = sm.layer[l];
         float *h_in = h_of(l), *h_mid = reinterpret_cast<float *>(S + sl.h_mid), *h_out = h_of(l + 1);
         char *y1 = S + sl.y1, *qkv = S + sl.qkv, *o = S + sl.o, *y2 = S + sl.y2, *gl = S + sl.g;
@@ -190,14 +191,14 @@ int forward_train(const ldit_cfg *cfg, const void *packed, const void *flat_para
         x2.Ypre = S + sl.a1;                       // gelu'(pre-activation), the backward's factor
         x3.Ypre = S + sl.z2; x3.rowscale = rowscale ? rowscale + (size_t)(2 * l + 1) * M : nullptr;
         LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bf16out(h_in, F32(pl.ln1_w), F32(pl.ln1_b), y1, M, C, cfg->ln_eps, stream));
-        LDIT_TRY(gemm(probe, y1, C, P + ml.wqkv, F32(pl.bqkv), qkv, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, none, stream));
+        LDIT_TRY(gemm(probe, y1, C, P + pl.wqkv / 2, F32(pl.bqkv), qkv, 3 * C, M, 3 * C, C, EPI_BIAS, nullptr, nullptr, nullptr, none, stream));
         LDIT_RUN(probe, LDIT_K_ATTENTION,
                  launch_attention_bf16_lse(qkv, qkv + 2 * (size_t)C, qkv + 4 * (size_t)C, o, reinterpret_cast<float *>(S + sl.lse),
                                            batch, g.T, g.H, g.D, 3 * C, 3 * C, 3 * C, C, scale, stream));
-        LDIT_TRY(gemm(probe, o, C, P + ml.wo, F32(pl.bo), h_mid, C, M, C, C, EPI_SCALE_RESID, F32(pl.lam1), h_in, nullptr, x1, stream));
+        LDIT_TRY(gemm(probe, o, C, P + pl.wo / 2, F32(pl.bo), h_mid, C, M, C, C, EPI_SCALE_RESID, F32(pl.lam1), h_in, nullptr, x1, stream));
         LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bf16out(h_mid, F32(pl.ln2_w), F32(pl.ln2_b), y2, M, C, cfg->ln_eps, stream));
-        LDIT_TRY(gemm(probe, y2, C, P + ml.w1, F32(pl.b1), gl, F, M, F, C, EPI_BIAS_GELU, nullptr, nullptr, nullptr, x2, stream));
-        LDIT_TRY(gemm(probe, gl, F, P + ml.w2, F32(pl.b2), h_out, C, M, C, F, EPI_SCALE_RESID, F32(pl.lam2), h_mid, tap, x3, stream));
+        LDIT_TRY(gemm(probe, y2, C, P + pl.w1 / 2, F32(pl.b1), gl, F, M, F, C, EPI_BIAS_GELU, nullptr, nullptr, nullptr, x2, stream));
+        LDIT_TRY(gemm(probe, gl, F, P + pl.w2 / 2, F32(pl.b2), h_out, C, M, C, F, EPI_SCALE_RESID, F32(pl.lam2), h_mid, tap, x3, stream));
         if (tap) LDIT_TRY(copy_taps(l + 1, h_out, tap));
     }
     return LDIT_OK;
@@ -246,7 +247,6 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, c
     if (ws_bytes < wm.total) return fail(LDIT_EWORKSPACE, "workspace %zu bytes < required %zu", ws_bytes, wm.total);
     const PackedMap gm = packed_map(g, LDIT_F32), &pm = gm;      // vectors are read from the flat fp32 master
     if (grads_bytes < gm.total) return fail(LDIT_EWORKSPACE, "gradient block %zu bytes < required %zu", grads_bytes, gm.total);
-    const PackedMap wm16 = packed_map(g, cfg->dtype);        // bf16 copies of the matrices (ldit_pack_train)
     for (int i = 0; dtaps && i < cfg->n_taps; ++i)
         if (dtaps[i] && !aligned16(dtaps[i])) return fail(LDIT_EINVAL, "backward: dtaps[%d] misaligned", i);
 
@@ -275,23 +275,23 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, c
                 LDIT_RUN(probe, LDIT_K_OTHER, launch_add_inplace(dh, static_cast<const float *>(dtaps[i]), act, stream));
         if (st == 0) break;
         const int l = st - 1;
-        const PackedLayer &pl = pm.layer[l], &gl = gm.layer[l], &wl = wm16.layer[l];
+        const PackedLayer &pl = pm.layer[l], &gl = gm.layer[l];
         const SavedLayer &sl = sm.layer[l];
         const float *rs1 = rowscale ? rowscale + (size_t)(2 * l) * M : nullptr, *rs2 = rowscale ? rowscale + (size_t)(2 * l + 1) * M : nullptr;
 
         // ---- MLP branch:  h_out = h_mid + rs2 lam2 (.) (gelu(y2 W1^T + b1) W2^T + b2) --------------------------------
         LDIT_RUN(probe, LDIT_K_OTHER, launch_resid_bwd(dh, S + sl.z2, F32(pl.lam2), rs2, dz, nullptr, M, C, Mp, PART(0), PART(1), stream));
         LDIT_TRY(wgrad(probe, jobs, dz, C, S + sl.g, F, GR(gl.w2), reinterpret_cast<float *>(ws + wm.slab[0]), C, F, M, zeros, stream));
-        LDIT_TRY(dgrad(probe, dz, C, W16 + wl.w2, da1, M, F, EPI_GELU_BWD, S + sl.a1, zeros, stream));          // da1 = (dz W2) (.) gelu'
+        LDIT_TRY(dgrad(probe, dz, C, W16 + gl.w2 / 2, da1, M, F, EPI_GELU_BWD, S + sl.a1, zeros, stream));          // da1 = (dz W2) (.) gelu'
         LDIT_RUN(probe, LDIT_K_OTHER, launch_colsum_bf16(da1, M, F, F, PART(2), stream));
         LDIT_TRY(wgrad(probe, jobs, da1, F, S + sl.y2, C, GR(gl.w1), reinterpret_cast<float *>(ws + wm.slab[1]), F, C, M, zeros, stream));
-        LDIT_TRY(dgrad(probe, da1, F, W16 + wl.w1, dy, M, C, EPI_F32, nullptr, zeros, stream));
+        LDIT_TRY(dgrad(probe, da1, F, W16 + gl.w1 / 2, dy, M, C, EPI_F32, nullptr, zeros, stream));
         LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bwd(dy, reinterpret_cast<const float *>(S + sl.h_mid), F32(pl.ln2_w), dh, M, C,
                                                               cfg->ln_eps, PART(3), PART(4), stream));
         // ---- attention branch:  h_mid = h_in + rs1 lam1 (.) (attn(LN1(h_in)) Wo^T + bo) --------------------------------
         LDIT_RUN(probe, LDIT_K_OTHER, launch_resid_bwd(dh, S + sl.z1, F32(pl.lam1), rs1, dz, nullptr, M, C, Mp, PART(5), PART(6), stream));
         LDIT_TRY(wgrad(probe, jobs, dz, C, S + sl.o, C, GR(gl.wo), reinterpret_cast<float *>(ws + wm.slab[2]), C, C, M, zeros, stream));
-        LDIT_TRY(dgrad(probe, dz, C, W16 + wl.wo, dob, M, C, EPI_BIAS, nullptr, zeros, stream));
+        LDIT_TRY(dgrad(probe, dz, C, W16 + gl.wo / 2, dob, M, C, EPI_BIAS, nullptr, zeros, stream));
         {
             const char *qkv = S + sl.qkv;
             LDIT_RUN(probe, LDIT_K_ATTENTION,
@@ -301,7 +301,7 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, c
         }
         LDIT_RUN(probe, LDIT_K_OTHER, launch_colsum_bf16(dqkv, M, 3 * C, 3 * C, PART(7), stream));
         LDIT_TRY(wgrad(probe, jobs, dqkv, 3 * C, S + sl.y1, C, GR(gl.wqkv), reinterpret_cast<float *>(ws + wm.slab[3]), 3 * C, C, M, zeros, stream));
-        LDIT_TRY(dgrad(probe, dqkv, 3 * C, W16 + wl.wqkv, dy, M, C, EPI_F32, nullptr, zeros, stream));
+        LDIT_TRY(dgrad(probe, dqkv, 3 * C, W16 + gl.wqkv / 2, dy, M, C, EPI_F32, nullptr, zeros, stream));
         LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bwd(dy, reinterpret_cast<const float *>(S + sl.h_in), F32(pl.ln1_w), dh, M, C,
                                                               cfg->ln_eps, PART(8), PART(9), stream));
         // ---- second stage of this layer's reductions: 4 wgrad slab sums (queued above) + 10 vectors, one launch ----------
@@ -380,31 +380,24 @@ size_t ldit_train_workspace_bytes(const ldit_cfg *cfg, int32_t batch)
     return train_ws_map(g, batch).total;
 }
 
-int ldit_pack_train(const ldit_cfg *cfg, const void *flat_params, void *packed, size_t packed_bytes, ldit_stream stream_)
+size_t ldit_train_mirror_bytes(const ldit_cfg *cfg)
+{
+    Geo g;
+    if (train_geometry(cfg, g) != LDIT_OK) return 0;
+    return packed_map(g, LDIT_F32).total / 2;
+}
+
+int ldit_pack_train(const ldit_cfg *cfg, const void *flat_params, void *mirror, size_t mirror_bytes, ldit_stream stream)
 {
     Geo g;
     LDIT_TRY(train_geometry(cfg, g));
-    if (!flat_params || !packed) return fail(LDIT_EINVAL, "pack_train: null pointer");
-    if (!aligned16(flat_params) || !aligned16(packed)) return fail(LDIT_EINVAL, "pack_train: pointers must be 16-byte aligned");
-    const PackedMap fm = packed_map(g, LDIT_F32), pm = packed_map(g, cfg->dtype);
-    if (packed_bytes < pm.total) return fail(LDIT_EWORKSPACE, "packed buffer %zu bytes < required %zu", packed_bytes, pm.total);
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const char *Fp = static_cast<const char *>(flat_params);
-    char *P = static_cast<char *>(packed);
-    const size_t C = g.C, F = g.F;
-    // bf16 copies of the four matrices per layer, in nn.Linear's own [out, in] layout: the forward reads them K-contiguous,
-    // the dgrad reads the same copy reduction-major, the wgrad needs no weight at all.  fp32 vectors are not copied.
-    auto mat = [&](size_t dst, size_t src, size_t n) -> int {
-        return launch_cvt_bf16(reinterpret_cast<const float *>(Fp + src), P + dst, n, stream);
-    };
-    for (int l = 0; l < g.L; ++l) {
-        const PackedLayer &d = pm.layer[l], &s = fm.layer[l];
-        LDIT_TRY(mat(d.wqkv, s.wqkv, 3 * C * C));
-        LDIT_TRY(mat(d.wo, s.wo, C * C));
-        LDIT_TRY(mat(d.w1, s.w1, F * C));
-        LDIT_TRY(mat(d.w2, s.w2, C * F));
-    }
-    return LDIT_OK;
+    if (!flat_params || !mirror) return fail(LDIT_EINVAL, "pack_train: null pointer");
+    if (!aligned16(flat_params) || !aligned16(mirror)) return fail(LDIT_EINVAL, "pack_train: pointers must be 16-byte aligned");
+    const size_t n = packed_map(g, LDIT_F32).total / 4;
+    if (mirror_bytes < 2 * n) return fail(LDIT_EWORKSPACE, "bf16 mirror %zu bytes < required %zu", mirror_bytes, 2 * n);
+    // one pass: the whole flat block rounded to bf16, same element layout (matrices stay in nn.Linear's [out, in] layout: the
+    // forward reads them K-contiguous, the dgrad reads the SAME copy reduction-major, the wgrad needs no weight)
+    return launch_cvt_bf16(static_cast<const float *>(flat_params), mirror, n, static_cast<hipStream_t>(stream));
 }
 
 int ldit_vit_forward_train(const ldit_cfg *cfg, const void *packed, const void *flat_params, const void *x, int32_t batch,
@@ -433,11 +426,12 @@ int ldit_vit_backward(const ldit_cfg *cfg, const void *flat_params, const void *
 }
 
 int ldit_adamw_step(void *params, const void *grads, void *exp_avg, void *exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
-                    float eps, float weight_decay, int32_t step, float grad_scale, ldit_stream stream)
+                    float eps, float weight_decay, int32_t step, float grad_scale, void *bf16_mirror, ldit_stream stream)
 {
     if (n < 0) return fail(LDIT_EINVAL, "adamw: negative length");
+    if (bf16_mirror && (reinterpret_cast<uintptr_t>(bf16_mirror) & 7u)) return fail(LDIT_EINVAL, "adamw: bf16 mirror misaligned");
     return launch_adamw(static_cast<float *>(params), static_cast<const float *>(grads), static_cast<float *>(exp_avg),
-                        static_cast<float *>(exp_avg_sq), (size_t)n, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                        static_cast<float *>(exp_avg_sq), (size_t)n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, bf16_mirror,
                         static_cast<hipStream_t>(stream));
 }
 

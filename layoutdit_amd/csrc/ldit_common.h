@@ -225,6 +225,6 @@ int launch_embed_bwd_small(const float *dh0, float *dpos, float *dcls, float *dp
 int launch_patches_transposed(const float *x, void *out, int B, int in_ch, int img_h, int img_w, int p, int Mp, hipStream_t stream);
 int launch_patches_rows(const float *x, void *out, int B, int in_ch, int img_h, int img_w, int p, hipStream_t stream);
 int launch_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1, float b2, float eps, float wd,
-                 int step, float grad_scale, hipStream_t stream);
+                 int step, float grad_scale, void *mirror, hipStream_t stream);
 
 }  // namespace ldit

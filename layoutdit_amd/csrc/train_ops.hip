@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256) zero_pad_columns(bf16_t *__restrict__ buf
 // g = grad * grad_scale (1 / world size after the all-reduce sum, times any loss-scale inverse).
 __global__ void __launch_bounds__(256) adamw_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                     float *__restrict__ v, size_t n4, float lr, float b1, float b2, float eps,
-                                                    float wd, float bc1, float bc2_sqrt, float grad_scale)
+                                                    float wd, float bc1, float bc2_sqrt, float grad_scale, bf16_t *__restrict__ mirror)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
@@ -441,6 +441,10 @@ __global__ void __launch_bounds__(256) adamw_kernel(float *__restrict__ p, const
         Vo[e] = vo;
     }
     reinterpret_cast<f32x4 *>(p)[i] = P;
+    if (mirror) {           // bf16 operand copy of the updated parameters, refreshed in the same pass (no separate re-pack)
+        const bf16x4 o = {(bf16_t)P[0], (bf16_t)P[1], (bf16_t)P[2], (bf16_t)P[3]};
+        reinterpret_cast<bf16x4 *>(mirror)[i] = o;
+    }
     reinterpret_cast<f32x4 *>(m)[i] = Mo;
     reinterpret_cast<f32x4 *>(v)[i] = Vo;
 }
@@ -577,7 +581,7 @@ int launch_patches_rows(const float *x, void *out, int B, int in_ch, int img_h, 
 }
 
 int launch_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1, float b2, float eps, float wd,
-                 int step, float grad_scale, hipStream_t stream)
+                 int step, float grad_scale, void *mirror, hipStream_t stream)
 {
     if (n == 0) return LDIT_OK;
     if (n % 4) return fail(LDIT_EINVAL, "adamw: length must be a multiple of 4");
@@ -585,7 +589,7 @@ int launch_adamw(float *p, const float *g, float *m, float *v, size_t n, float l
     if (step < 1) return fail(LDIT_EINVAL, "adamw: step counts from 1");
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     LAUNCH_CHECKED(adamw_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v, n / 4, lr, b1, b2, eps, wd,
-                   (float)bc1, (float)sqrt(bc2), grad_scale);
+                   (float)bc1, (float)sqrt(bc2), grad_scale, static_cast<bf16_t *>(mirror));
     return LDIT_OK;
 }
 

@@ -104,7 +104,7 @@ class FlatState:
                 view.copy_(p.data)
                 p.data = view
         # scratch of the library, sized once per batch size
-        self.packed = torch.empty(lib.ldit_packed_bytes(C.byref(self.lcfg)), dtype=torch.uint8, device=self.device)
+        self.packed = torch.empty(lib.ldit_train_mirror_bytes(C.byref(self.lcfg)), dtype=torch.uint8, device=self.device)   # bf16 mirror
         self._packed_version = None
         self._ws: Dict[int, torch.Tensor] = {}
 
@@ -130,7 +130,7 @@ class FlatState:
         return tuple(p._version for _, p, _, _ in self.named)
 
     def repack(self, force: bool = False) -> None:
-        """flat fp32 parameters -> bf16 operand copies of the matrices, when they changed."""
+        """flat fp32 parameters -> their bf16 mirror (one pass), when a parameter's version changed."""
         v = self.version()
         if force or v != self._packed_version:
             with torch.cuda.device(self.device):
@@ -329,8 +329,8 @@ class TrainStep:
         with torch.cuda.device(st.device):
             _lib.check(_lib.load().ldit_adamw_step(st.params.data_ptr(), st.grads.data_ptr(), self.exp_avg.data_ptr(),
                                                    self.exp_avg_sq.data_ptr(), st.numel, self.lr, self.betas[0], self.betas[1],
-                                                   self.eps, self.wd, self.steps, 1.0 / self.world,
+                                                   self.eps, self.wd, self.steps, 1.0 / self.world, st.packed.data_ptr(),
                                                    torch.cuda.current_stream(st.device).cuda_stream))
-        st.repack(force=True)
+        st._packed_version = st.version()     # the update refreshed the bf16 mirror itself
         self.encoder._packed_key = None       # the eval path's packed copy (DiTEncoder._pack) is stale now
         return taps

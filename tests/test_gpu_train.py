@@ -188,11 +188,13 @@ def test_fused_adamw_matches_torch(wd):
         ref.grad = torch.from_numpy(g).double() * 0.5
         opt.step()
         gd = torch.from_numpy(g).to(DEV)
+        mirror = torch.empty(n, dtype=BF, device=DEV)
         _lib.check(lib.ldit_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-2, 0.9, 0.999, 1e-8, wd,
-                                       i + 1, 0.5, _stream()))
+                                       i + 1, 0.5, mirror.data_ptr() if i == 2 else None, _stream()))
     assert rel_l2(p.cpu().numpy(), ref.detach().numpy()) < 1e-6
+    assert torch.equal(mirror, p.to(BF))                    # the bf16 mirror of the updated parameters, same pass
     assert lib.ldit_adamw_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-2, 0.9, 0.999, 1e-8, wd, 0, 1.0,
-                               _stream()) == _lib.LDIT_EINVAL
+                               None, _stream()) == _lib.LDIT_EINVAL
 
 
 # ---- whole path -----------------------------------------------------------------------------------------------------------------------
