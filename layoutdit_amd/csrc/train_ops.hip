@@ -300,9 +300,38 @@ __global__ void __launch_bounds__(256) layernorm_bwd_rows(const float *__restric
 // job j: out[n] = sum_{p < P} part[p * stride + n], n < N (fixed order).  grid.x = sum over jobs of ceil(N / 1024).
 __global__ void __launch_bounds__(256) reduce_jobs_kernel(const ReduceJobs jobs)
 {
+    __shared__ f32x4 red[16][16];
     int blk = blockIdx.x, j = 0;
     while (j + 1 < jobs.n && blk >= jobs.first_block[j + 1]) ++j;
     blk -= jobs.first_block[j];
+    if (jobs.P[j] > 16) {
+        // TALL job (a bias / gamma / lambda gradient: hundreds of partial rows, a few thousand columns): a workgroup owns 64
+        // columns, 16 row groups of 16 column quads - each thread walks P / 16 rows, then a fixed-order LDS sum.  (One thread
+        // per column quad walking all 512 partial rows was a serial chain of ~128 memory round trips: 80 us per layer.)
+        const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+        const int64_t n = (int64_t)blk * 64 + cq * 4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (n < jobs.N[j]) {
+            const float *p = jobs.part[j] + n;
+            const int64_t st = jobs.stride[j];
+            for (int q = rg; q < jobs.P[j]; q += 16) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (int64_t)q * st);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] += a[e];
+            }
+        }
+        red[rg][cq] = s;
+        __syncthreads();
+        if (rg == 0 && n < jobs.N[j]) {
+            f32x4 t = red[0][cq];
+#pragma unroll
+            for (int g = 1; g < 16; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] += red[g][cq][e];
+            *reinterpret_cast<f32x4 *>(jobs.out[j] + n) = t;
+        }
+        return;
+    }
     const int64_t n = ((int64_t)blk * 256 + threadIdx.x) * 4;      // four consecutive outputs per thread (16-byte accesses)
     if (n >= jobs.N[j]) return;
     const float *p = jobs.part[j] + n;
@@ -534,7 +563,7 @@ int launch_reduce_jobs(ReduceJobs &jobs, hipStream_t stream)
         if ((jobs.N[j] & 3) || (jobs.stride[j] & 3) || (reinterpret_cast<uintptr_t>(jobs.part[j]) & 15u) || (reinterpret_cast<uintptr_t>(jobs.out[j]) & 15u))
             return fail(LDIT_EINVAL, "reduce: lengths and strides must be multiples of 4 floats, pointers 16-byte aligned");
         jobs.first_block[j] = blocks;
-        blocks += (int)((jobs.N[j] / 4 + 255) / 256);
+        blocks += jobs.P[j] > 16 ? (int)((jobs.N[j] + 63) / 64) : (int)((jobs.N[j] / 4 + 255) / 256);
     }
     LAUNCH_CHECKED(reduce_jobs_kernel, dim3(blocks), dim3(256), 0, stream, jobs);
     jobs.n = 0;
