@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
     constexpr int NWAVES = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NLD = (BM + BN) / (8 * NWAVES);
     constexpr int A_BYTES = BM * ROWB, STAGE = (BM + BN) * ROWB;
-    static_assert((BM == 128 || BM == 256) && (BN == 128 || BN == 256), "reduction-major images need 256- or 512-byte rows");
+    static_assert((!TA || BM == 128 || BM == 256) && (BN == 128 || BN == 256), "reduction-major images need 256- or 512-byte rows");
     static_assert((BM + BN) % (8 * NWAVES) == 0, "DMA pieces must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -216,11 +216,25 @@ int launch_tr(const GemmArgsH &a, hipStream_t stream)
 template <int EPI, bool TA>
 int launch_tr_tiled(const GemmArgsH &a, hipStream_t stream)
 {
-    // 256 x 256 (8 waves) when that fills most of a round, else 128 x 128 (4 waves, two workgroups per CU)
+    // 256 x 256 (8 waves) when that fills most of a round, else 128 x 128 (4 waves, two workgroups per CU).  A K-contiguous A
+    // operand (dgrad) may also take the 192- and 320-row tiles of gemm_bf16.hip against round quantisation: whole rounds of 256
+    // workgroups, priced as rounds x tile height.
     const long t256 = (long)a.x.splits * ((a.M + 255) / 256) * ((a.N + 255) / 256);
     int pick = t256 >= 120 ? 3 : 2;
+    if (!TA && pick == 3) {
+        double best = (double)((t256 + 255) / 256);
+        for (int bm : {192, 320}) {
+            const long t = (long)((a.M + bm - 1) / bm) * ((a.N + 255) / 256);
+            const double c = (double)((t + 255) / 256) * (bm / 256.0) * 1.03;
+            if (c < best) { best = c; pick = bm == 192 ? 4 : 5; }
+        }
+    }
     if (const char *force = getenv("LDIT_GEMM_BF16_TR_TILE"))
-        if ((force[0] == '2' || force[0] == '3') && force[1] == 0) pick = force[0] - '0';
+        if (force[0] >= '2' && force[0] <= (TA ? '3' : '5') && force[1] == 0) pick = force[0] - '0';
+    if constexpr (!TA) {
+        if (pick == 4) return launch_tr<2, 4, 3, 2, EPI, TA>(a, stream);
+        if (pick == 5) return launch_tr<2, 4, 5, 2, EPI, TA>(a, stream);
+    }
     if (pick == 3) return launch_tr<2, 4, 4, 2, EPI, TA>(a, stream);
     return launch_tr<2, 2, 2, 2, EPI, TA>(a, stream);
 }
