@@ -179,6 +179,11 @@ int ldit_embed_f32(const void *x, const void *patch_w, const void *patch_b, cons
 int ldit_tap_to_map_f32(const void *tap, void *out, int64_t B, int64_t Gh, int64_t Gw, int64_t C, float scale,
                         ldit_stream stream);
 
+/* Adjoint of ldit_tap_to_map_f32 (training through DiTBackbone.forward, ref dit_backbone.py:50-61 under loss.backward()):
+ * dmap [B,C,Gh*scale,Gw*scale] NCHW contiguous -> dtap [B,1+Gh*Gw,C] (CLS row = 0).  Gather form, no atomics. */
+int ldit_tap_to_map_bwd_f32(const void *dmap, void *dtap, int64_t B, int64_t Gh, int64_t Gw, int64_t C, float scale,
+                            ldit_stream stream);
+
 /* ---- bf16 path (first build; BASELINE configs 3-5) ------------------------------------------------------------------
  * Y[M,N] = epilogue(X[M,K] . W[N,K]^T), X and W bf16 (K-contiguous), fp32 accumulation on v_mfma_f32_32x32x16_bf16.
  * K % 64 == 0, lda % 8 == 0.  bias / lam fp32.  LDIT_EPI_BIAS and LDIT_EPI_BIAS_GELU write bf16 Y;

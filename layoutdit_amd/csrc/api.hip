@@ -339,6 +339,14 @@ int ldit_tap_to_map_f32(const void *tap, void *out, int64_t B, int64_t Gh, int64
                              scale, static_cast<hipStream_t>(stream));
 }
 
+int ldit_tap_to_map_bwd_f32(const void *dmap, void *dtap, int64_t B, int64_t Gh, int64_t Gw, int64_t C, float scale, ldit_stream stream)
+{
+    if (B * (Gh * Gw + 1) * C >= (1ll << 31) || (double)B * C * Gh * Gw * scale * scale >= 2147483648.0)
+        return fail(LDIT_EUNSUPPORTED, "tap_to_map_bwd: operand exceeds 2^31 elements");
+    return launch_tap_to_map_bwd(static_cast<const float *>(dmap), static_cast<float *>(dtap), (int)B, (int)Gh, (int)Gw, (int)C, scale,
+                                 static_cast<hipStream_t>(stream));
+}
+
 int ldit_linear_bf16(const void *X, int64_t lda, const void *W, const void *bias, void *Y, int64_t ldy, int64_t M,
                      int64_t N, int64_t K, int32_t epilogue, const void *lam, const void *R, void *Y2, ldit_stream stream)
 {

@@ -160,6 +160,7 @@ int launch_attention(const float *Q, const float *K, const float *V, float *O, i
                      int ldk, int ldv, int ldo, float scale, hipStream_t stream);
 int launch_cls_rows(const float *cls, const float *pos, float *out, int B, int tokens, int C, hipStream_t stream);
 int launch_tap_to_map(const float *tap, float *out, int B, int Gh, int Gw, int C, float scale, hipStream_t stream);
+int launch_tap_to_map_bwd(const float *dmap, float *dtap, int B, int Gh, int Gw, int C, float scale, hipStream_t stream);
 int launch_preprocess(const void *const *images, bool half_in, const int *heights, const int *widths, int B, int in_ch, float mean,
                       float std, int out_h, int out_w, float *out, hipStream_t stream);
 int launch_cast_f16(const void *src, void *dst, size_t n, bool widen, hipStream_t stream);

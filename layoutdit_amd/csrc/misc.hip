@@ -333,3 +333,67 @@ int launch_fpn_merge(const float *lat, const float *top, float *out, int B, int 
 }
 
 }  // namespace ldit
+
+// ---- adjoint of tap_to_map (training through DiTBackbone.forward, ref dit_backbone.py:50-61) -----------------------------
+// dtap[b, 1 + gy Gw + gx, c] = sum over the output pixels whose bilinear footprint contains token (gy, gx) of weight x
+// dmap[b, c, oy, ox]; the CLS row receives zero (it is sliced away by the forward).  Gather form: every gradient element
+// is written by exactly one thread, in a fixed order - no atomics.  The weights are recomputed with the forward's own index
+// arithmetic, so clamping at the borders is the exact transpose of the forward.
+namespace ldit {
+namespace {
+
+__device__ __forceinline__ float axis_weight(int o, int g, int G, float inv_scale)
+{
+    float s = ((float)o + 0.5f) * inv_scale - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    int i0 = (int)s;
+    i0 = i0 > G - 1 ? G - 1 : i0;
+    const int i1 = i0 + (i0 < G - 1);
+    const float l = s - (float)i0;
+    return (i0 == g ? 1.f - l : 0.f) + (i1 == g ? l : 0.f);
+}
+
+__global__ void __launch_bounds__(256) tap_to_map_bwd(const float *__restrict__ dmap, float *__restrict__ dtap, int B, int Gh, int Gw,
+                                                      int C, int Oh, int Ow, float scale)
+{
+    const size_t total = (size_t)B * C * Gh * Gw, idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int gx = (int)(idx % Gw);
+    size_t t = idx / Gw;
+    const int gy = (int)(t % Gh);
+    t /= Gh;
+    const int c = (int)(t % C), b = (int)(t / C);
+    const float inv = 1.0f / scale;
+    int ylo = (int)floorf(scale * (float)(gy - 1)) - 1, yhi = (int)ceilf(scale * (float)(gy + 2)) + 1;
+    int xlo = (int)floorf(scale * (float)(gx - 1)) - 1, xhi = (int)ceilf(scale * (float)(gx + 2)) + 1;
+    ylo = ylo < 0 ? 0 : ylo; xlo = xlo < 0 ? 0 : xlo;
+    yhi = yhi > Oh - 1 ? Oh - 1 : yhi; xhi = xhi > Ow - 1 ? Ow - 1 : xhi;
+    const float *plane = dmap + ((size_t)b * C + c) * Oh * Ow;
+    float acc = 0.0f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+        const float wy = axis_weight(oy, gy, Gh, inv);
+        if (wy == 0.0f) continue;
+        float row = 0.0f;
+        for (int ox = xlo; ox <= xhi; ++ox) row += axis_weight(ox, gx, Gw, inv) * plane[(size_t)oy * Ow + ox];
+        acc += wy * row;
+    }
+    dtap[((size_t)b * (Gh * Gw + 1) + 1 + gy * Gw + gx) * C + c] = acc;
+    if (gy == 0 && gx == 0) dtap[(size_t)b * (Gh * Gw + 1) * C + c] = 0.0f;      // CLS row
+}
+
+}  // namespace
+
+int launch_tap_to_map_bwd(const float *dmap, float *dtap, int B, int Gh, int Gw, int C, float scale, hipStream_t stream)
+{
+    if (B <= 0 || Gh <= 0 || Gw <= 0 || C <= 0) return fail(LDIT_EINVAL, "tap_to_map_bwd: empty problem");
+    if (!(scale == 4.0f || scale == 2.0f || scale == 1.0f || scale == 0.5f)) return fail(LDIT_EUNSUPPORTED, "tap_to_map_bwd: scale %g not in {4,2,1,0.5}", (double)scale);
+    if (!dmap || !dtap) return fail(LDIT_EINVAL, "tap_to_map_bwd: null operand");
+    const int Oh = (int)((float)Gh * scale), Ow = (int)((float)Gw * scale);
+    if (Oh <= 0 || Ow <= 0) return fail(LDIT_EINVAL, "tap_to_map_bwd: map collapses to zero size");
+    const size_t total = (size_t)B * C * Gh * Gw;
+    hipLaunchKernelGGL(tap_to_map_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dmap, dtap, B, Gh, Gw, C, Oh, Ow, scale);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
+
+}  // namespace ldit

@@ -56,7 +56,8 @@ class DiTBackbone(nn.Module):
             else:
                 # the encoder returns fp32 contiguous taps for fp32 input: no host-side copies on that path
                 src = h if (h.dtype == torch.float32 and h.is_contiguous()) else h.float().contiguous()
-                t = ops.tap_to_map(src, Gh, Gw, scale)
+                # under autograd (train mode) the rescale carries its adjoint kernel: gradients reach the encoder
+                t = ops.tap_to_map_autograd(src, Gh, Gw, scale) if src.requires_grad else ops.tap_to_map(src, Gh, Gw, scale)
                 if t.dtype != h.dtype:
                     t = t.to(h.dtype)
             feats[f"p{i}"] = t

@@ -143,6 +143,29 @@ def narrow_f16(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class _TapToMapFn(torch.autograd.Function):
+    """tap_to_map with its adjoint (ldit_tap_to_map_bwd_f32), so DiTBackbone.forward stays differentiable in train mode."""
+
+    @staticmethod
+    def forward(ctx, tap, gh, gw, scale):
+        ctx.geom = (gh, gw, float(scale))
+        return tap_to_map(tap.detach(), gh, gw, scale)
+
+    @staticmethod
+    def backward(ctx, dmap):
+        gh, gw, scale = ctx.geom
+        lib = _lib.load()
+        dmap = _req(dmap.contiguous(), "dmap")
+        B, Cc = dmap.shape[0], dmap.shape[1]
+        dtap = torch.empty((B, gh * gw + 1, Cc), device=dmap.device, dtype=torch.float32)
+        _launch(_device(dmap), lib.ldit_tap_to_map_bwd_f32, _ptr(dmap), _ptr(dtap), B, gh, gw, Cc, scale)
+        return dtap, None, None, None
+
+
+def tap_to_map_autograd(tap: torch.Tensor, gh: int, gw: int, scale: float) -> torch.Tensor:
+    return _TapToMapFn.apply(tap, gh, gw, scale)
+
+
 def preprocess(images: Sequence[torch.Tensor], size=224, mean: float = 0.5, std: float = 0.5) -> torch.Tensor:
     """The detector's input transform in one kernel (ref src/layoutdit/modeling/model.py:50-54: fixed_size 224,
     mean = std = 0.5): list of ``[3, h, w]`` images in [0, 1] (all fp32 or all fp16) -> normalised, bilinearly resized

@@ -126,3 +126,56 @@ def test_encoder_accepts_fp16_pixels_without_a_host_cast():
         assert torch.equal(h16[t], h32[t].half())
     with pytest.raises(ValueError, match="float32 or float16"):
         m(x.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("gh,gw,scale", [(14, 14, 4.0), (14, 14, 2.0), (14, 14, 0.5), (6, 4, 4.0), (5, 7, 0.5), (3, 3, 2.0)])
+def test_tap_to_map_adjoint(gh, gw, scale):
+    """Backward of the tap post-processing (ref dit_backbone.py:50-61 under loss.backward()): the gather-form adjoint kernel
+    against torch autograd of the same F.interpolate call."""
+    B, Cc = 2, 64
+    tap = _rand(30, B, gh * gw + 1, Cc)
+    w = _rand(31, B, Cc, int(gh * scale), int(gw * scale))
+    t = torch.from_numpy(tap).to(DEV).requires_grad_(True)
+    m = ops.tap_to_map_autograd(t, gh, gw, scale)
+    (m * torch.from_numpy(w).to(DEV)).sum().backward()
+    r = torch.from_numpy(tap).double().requires_grad_(True)
+    rm = F.interpolate(r[:, 1:, :].permute(0, 2, 1).reshape(B, Cc, gh, gw), scale_factor=scale, mode="bilinear", align_corners=False)
+    (rm * torch.from_numpy(w).double()).sum().backward()
+    assert rel_l2(m.detach().cpu().numpy(), rm.detach().numpy()) < 1e-6
+    assert rel_l2(t.grad.cpu().numpy(), r.grad.numpy()) < 1e-6
+    assert float(t.grad[:, 0].abs().max()) == 0.0                 # the CLS token is sliced away
+
+
+def test_backbone_train_mode_is_differentiable():
+    """DiTBackbone.forward under autograd (the reference trains through it): gradients flow from p2..p5 through the rescale
+    adjoint into the encoder's backward; compared with the float64 autograd oracle of the whole chain."""
+    from layoutdit_amd.modeling import DiTBackbone
+    from oracle.vit_oracle_torch import train_reference
+    cfg = cfgs.vit_micro()
+    cfg.drop_path_rate = 0.0
+    cfg.taps = [1, 1, 2, 3]
+    w = synth.synth_weights(cfg, 3)
+    x = synth.synth_images(2, 64, 64, seed=5, kind="uniform")
+    bb = DiTBackbone(config=cfg, compute_dtype="bf16")
+    bb.dit.load_numpy(w)
+    bb = bb.to(DEV).train()
+    feats = bb(torch.from_numpy(x).to(DEV))
+    ws = [torch.from_numpy(_rand(40 + i, *f.shape, scale=1.0 / np.sqrt(f.numel()))).to(DEV) for i, f in enumerate(feats.values())]
+    sum((f * wi).sum() for f, wi in zip(feats.values(), ws)).backward()
+    torch.cuda.synchronize()
+    # oracle: upstream gradient at each tap = adjoint of the reference's own post-processing, by torch autograd on the CPU
+    g = 4
+    dtaps = []
+    for (name, f), wi, s in zip(feats.items(), ws, bb.scales):
+        t = torch.zeros(2, g * g + 1, cfg.hidden_size, dtype=torch.float64, requires_grad=True)
+        m = t[:, 1:, :].permute(0, 2, 1).reshape(2, cfg.hidden_size, g, g)
+        if s != 1.0:
+            m = F.interpolate(m, scale_factor=s, mode="bilinear", align_corners=False)
+        (m * wi.cpu().double()).sum().backward()
+        dtaps.append(t.grad.float().numpy())
+    _, ref = train_reference(cfg, w, x, dtaps, taps=bb.layer_idxs)
+    st = bb.dit._flat_state
+    got = {name: p.grad.detach().cpu().numpy() for name, p, _, _ in st.named}
+    for short, hf in (("0.w1", "encoder.layer.0.intermediate.dense.weight"), ("2.wq", "encoder.layer.2.attention.attention.query.weight"),
+                      ("patch_w", "embeddings.patch_embeddings.projection.weight"), ("1.lam2", "encoder.layer.1.lambda_2")):
+        assert rel_l2(got[short], ref[hf]) < 3e-2, short
