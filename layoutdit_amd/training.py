@@ -255,7 +255,7 @@ class TrainStep:
     def __init__(self, encoder, rank: Optional[Rank] = None, lr: float = 1e-4, weight_decay: float = 0.0,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, seed: int = 0,
                  dtaps: Optional[Sequence[torch.Tensor]] = None, drop_path_rate: Optional[float] = None,
-                 img_size: Optional[Tuple[int, int]] = None):
+                 img_size: Optional[Tuple[int, int]] = None, force_comm: bool = False):
         cfg = encoder.config
         if encoder.compute_dtype != "bf16":
             raise NotImplementedError("the train step exists for compute_dtype='bf16' only (BASELINE configs[2])")
@@ -274,6 +274,9 @@ class TrainStep:
         self._dtaps_seed = seed
         self._saved = None
         self.world = rank.world if rank else 1
+        # force_comm: run the staged backward + per-layer bucket all-reduce even with one rank (rehearses the RCCL path on a
+        # one-GPU box: a one-rank all-reduce is the identity)
+        self.comm = self.world > 1 or (force_comm and rank is not None and dist.is_initialized())
 
     @property
     def flat_params(self) -> torch.Tensor:
@@ -316,7 +319,7 @@ class TrainStep:
         dt = self._upstream(x)
         taps = st.forward(x, self.taps, drop_scales, saved, _timing)
         works = []
-        if self.world > 1:
+        if self.comm:
             for stage in range(L, -1, -1):                       # one bucket per layer, reduced while the next layers run
                 st.backward(x, self.taps, dt, drop_scales, saved, stage, stage, _timing)
                 works.append(self._all_reduce(st.bucket(stage)))

@@ -146,3 +146,33 @@ def test_train_step_two_ranks_average_gradients():
     mo, vo = 0.1 * g, 0.001 * g * g
     want = p0.astype(np.float64) - (1e-3 / 0.1) * mo / (np.sqrt(vo) / np.sqrt(0.001) + 1e-8)
     assert np.abs(n0 - want).max() < 2e-6
+
+
+def test_train_step_bucketed_all_reduce_over_rccl_one_rank():
+    """The `nccl` branch of TrainStep - staged backward, one async all-reduce per layer bucket on RCCL's stream, wait, fused
+    AdamW - with a one-rank RCCL group on the box's GPU: must equal the un-staged single-process step bit for bit."""
+    import subprocess
+    import sys
+    code = (
+        "import torch\n"
+        "from layoutdit_amd import config as cfgs, dp, synth, training\n"
+        "from layoutdit_amd.modeling import DiTEncoder\n"
+        "from tests.golden.make_golden_grad import upstream\n"
+        "r = dp.init(backend='nccl', force_group=True)\n"
+        "cfg = cfgs.vit_micro()\n"
+        "x = torch.from_numpy(synth.synth_images(4, 64, 64, seed=5, kind='uniform')).to('cuda:0')\n"
+        "dt = [torch.from_numpy(d).to('cuda:0') for d in upstream(cfg, 4, cfg.tokens(64, 64), 9)]\n"
+        "out = []\n"
+        "for rank, force in ((r, True), (None, False)):\n"
+        "    m = DiTEncoder(cfg, compute_dtype='bf16').load_numpy(synth.synth_weights(cfg, 3)).to('cuda:0').train()\n"
+        "    st = training.TrainStep(m, rank, lr=1e-3, dtaps=dt, drop_path_rate=0.0, img_size=(64, 64), force_comm=force)\n"
+        "    assert st.comm == force\n"
+        "    st.step(x); st.step(x)\n"
+        "    torch.cuda.synchronize(); out.append((st.state.grads.clone(), st.flat_params.clone()))\n"
+        "assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])\n"
+        "dp.finalize(r); print('rccl-train-ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert res.returncode == 0 and "rccl-train-ok" in res.stdout, res.stderr[-3000:]
