@@ -17,6 +17,7 @@
 // element), fp32, lane-local apart from one lane<->lane+32 exchange.  Four waves (128 queries) per workgroup, 32 KB of
 // LDS and 128 VGPRs: four workgroups per CU, so on every SIMD one wave's softmax VALU work overlaps another's MFMAs.
 #include <cstdlib>
+#include <type_traits>
 
 #include "ldit_common.h"
 
@@ -111,6 +112,7 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
     for (int e = 0; e < 16; ++e) { o[0][e] = 0.0f; o[1][e] = 0.0f; }
     float m_run = -INFINITY, l_run = 0.0f;
     const float c = scale * 1.44269504088896340736f;     // softmax in the exp2 domain
+    const float lazy = 8.0f / c;                         // deferred-rescale threshold in raw-score units (2^8 in the exp2 domain)
     const int sw = (c32 >> 1) & 7;
     // transposing read: lane 4q+p of a 16-lane group addresses key q, d 4p..4p+3 of the group's 16 columns
     const int vlane = 64 * ((lane & 15) >> 2) + 32 * ((lane >> 4) & 1) + 8 * (lane & 3) + 512 * h;
@@ -121,11 +123,15 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
     issue(0, 0);
-    for (int ci = 0; ci < nchunks; ++ci) {
+    // One chunk: wait for its K/V images, start the next chunk's DMA, multiply.  Instantiated per number of live 32-key tiles
+    // so that the score registers are straight-line values inside it (per-tile `if (kt < ktiles)` guards made every tile a
+    // phi and cost ~40 v_mov per chunk): the loop below runs the full chunks, the short last chunk is peeled behind it (a
+    // last chunk of N = 197 skips its dead tile).  Two instantiations INSIDE the loop spill at 128 registers; peeled they do not.
+    auto step = [&](const int ci, auto nkt_c) {
+        constexpr int NKT = decltype(nkt_c)::value;
         ATT_STAMP(t0);
         const int c0 = ci * KC;
         const int nkeys = (N - c0) < KC ? (N - c0) : KC;
-        const int ktiles = (nkeys + 31) >> 5;
         // ONE barrier per chunk: behind it every wave's pieces of chunk ci have landed AND every wave has finished
         // multiplying chunk ci-1 (program order), so the other stage is free - chunk ci+1 is issued right here and has the
         // whole of chunk ci's arithmetic to land.
@@ -141,13 +147,12 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
         if (active) {
             const char *Ks = smem + (ci & 1) * STAGE;
             const char *Vs = Ks + HALF;
-            // ---- S^T = K . Q^T -------------------------------------------------------------------------------------
-            f32x16 s[KT];
-            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            {
+                // ---- S^T = K . Q^T ---------------------------------------------------------------------------------
+                f32x16 s[NKT];
+                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                s[kt] = zero16;
-                if (kt < ktiles) {
+                for (int kt = 0; kt < NKT; ++kt) {
                     const char *kr = Ks + (kt * 32 + c32) * KROWB;
 #pragma unroll
                     for (int st = 0; st < 4; ++st) {
@@ -155,57 +160,55 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
                         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], st ? s[kt] : zero16, 0, 0, 0);
                     }
                 }
-            }
-            ATT_STAMP(t3);
-            // ---- mask padded keys (last chunk only: a real branch, not 2 VALU ops on every score), running max on the raw
-            //      scores (scale > 0 commutes with max) ---------------------------------------------------------------------
-            if (nkeys < KC) {
+                ATT_STAMP(t3);
+                // ---- mask padded keys (last chunk only: a real branch, not 2 VALU ops on every score), running max on
+                //      the raw scores (scale > 0 commutes with max) ------------------------------------------------------
+                if (nkeys < NKT * 32) {
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt)
+                    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if ((kt * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) >= nkeys) s[kt][r] = -INFINITY;
-            }
-            float mx = -INFINITY;
+                        for (int r = 0; r < 16; ++r)
+                            if ((kt * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) >= nkeys) s[kt][r] = -INFINITY;
+                }
+                float mx = -INFINITY;
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                if (kt < ktiles) {
+                for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-                }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-            const float mc = m_new * c;
-            m_run = m_new;
-            float lsum = 0.0f;
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                // Deferred rescale: the running maximum only moves when a chunk beats it by more than 2^8 in the exp2
+                // domain (always on the first chunk, m_run = -inf).  Until then p = exp2(c s - c m_run) may exceed 1 by up
+                // to 2^8 - harmless in fp32 sums and in bf16 P (a power-of-two scale of the same mantissas) - and the 32
+                // accumulator multiplies, the alpha exp2 and the l rescale are skipped behind a wave-uniform branch.
+                const bool grow = mx > m_run + lazy;
+                if (__builtin_amdgcn_ballot_w64(grow)) {
+                    const float m_new = grow ? mx : m_run;
+                    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);      // 1 for lanes that keep m_run
+                    m_run = m_new;
+                    l_run *= alpha;
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                if (kt < ktiles) {
+                    for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+                }
+                const float mc = m_run * c;
+                float lsum = 0.0f;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c, -mc));
                         s[kt][r] = pv;
                         lsum += pv;
                     }
-                }
-            }
-            l_run = l_run * alpha + lsum;
-            if (ci) {
+                l_run += lsum;
+                ATT_STAMP(t4);
+                // ---- O^T += V^T . P^T -----------------------------------------------------------------------------------
+                // The transposing reads are inline asm: through the builtin, hipcc cannot tell that they do not alias the
+                // LDS-DMA writes of the NEXT chunk and guards each group with s_waitcnt vmcnt(0), which would serialise
+                // the double buffer.  Asm reads are invisible to the compiler's waitcnt pass, hence the explicit
+                // lgkmcnt(0) and the sched_barrier that keeps the MFMAs below it.
+                const unsigned vaddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) const char *)(Vs + vlane));
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
-            }
-            ATT_STAMP(t4);
-            // ---- O^T += V^T . P^T ---------------------------------------------------------------------------------------
-            // The transposing reads are inline asm: through the builtin, hipcc cannot tell that they do not alias the
-            // LDS-DMA writes of the NEXT chunk and guards each group with s_waitcnt vmcnt(0), which would serialise the
-            // double buffer.  Asm reads are invisible to the compiler's waitcnt pass, hence the explicit lgkmcnt(0) and
-            // the sched_barrier that keeps the MFMAs below it.
-            const unsigned vaddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) const char *)(Vs + vlane));
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                if (kt < ktiles) {
+                for (int kt = 0; kt < NKT; ++kt) {
                     // block (key group, d half) = ((32 kt + 16 st + 8 u + 4 h) / 4) * 2 + dt; h is in vlane
                     s16x4 vr[2][2][2];                 // [st][dt][u]
 #pragma unroll
@@ -233,14 +236,20 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
                             o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.f, pf[st], o[dt], 0, 0, 0);
                         }
                 }
-            }
 #ifdef LDIT_GEMM_STAMPS
-            asm volatile("s_nop 0" :: "v"(o[0][0]), "v"(o[1][0]));
-            const unsigned long long t5 = __builtin_amdgcn_s_memtime();
-            ts += t3 - t2; tx += t4 - t3; tp += t5 - t4;
+                asm volatile("s_nop 0" :: "v"(o[0][0]), "v"(o[1][0]));
+                const unsigned long long t5 = __builtin_amdgcn_s_memtime();
+                ts += t3 - t2; tx += t4 - t3; tp += t5 - t4;
 #endif
+            }
         }
-    }
+    };
+    const int last_tiles = (N - (nchunks - 1) * KC + 31) >> 5;
+    for (int ci = 0; ci + 1 < nchunks; ++ci) step(ci, std::integral_constant<int, KT>{});
+    if (last_tiles == KT) step(nchunks - 1, std::integral_constant<int, KT>{});
+    else if (KT == 4 && last_tiles == 3) step(nchunks - 1, std::integral_constant<int, KT == 4 ? 3 : 1>{});
+    else if (KT == 4 && last_tiles == 2) step(nchunks - 1, std::integral_constant<int, KT == 4 ? 2 : 1>{});
+    else step(nchunks - 1, std::integral_constant<int, 1>{});
 
 #ifdef LDIT_GEMM_STAMPS
     if (g_attn_stamps && wave == 0 && lane == 0) {
