@@ -394,6 +394,16 @@ int launch_gemm(const GemmArgs &a, int epi, int amode, hipStream_t stream)
         if ((a.patch & 3) || (a.img_w & 3)) return fail(LDIT_EUNSUPPORTED, "gemm: patch and image width must be multiples of 4");
         return launch_tiled<EPI_EMBED, A_PATCH>(a, stream);
     }
+    // serving-size batches: the 32 x 32 / 16x16x4 kernel (same k order, bit-identical results; gemm_thin_f32.hip).
+    // LDIT_GEMM_TILE=4 forces it for any M, 0..3 force one of the big tilings (tests cover every instantiation that way).
+    {
+        const char *force = getenv("LDIT_GEMM_TILE");
+        const bool thin = force ? (force[0] == '4' && force[1] == 0) : a.M <= gemm_thin_max_rows();
+        if (thin && epi >= EPI_BIAS && epi <= EPI_SCALE_RESID) {
+            if (epi == EPI_SCALE_RESID && (!a.lam || !a.R)) return fail(LDIT_EINVAL, "gemm: scale+residual epilogue needs lam and R");
+            return launch_gemm_thin(a, epi, stream);
+        }
+    }
     switch (epi) {
         case EPI_BIAS: return launch_tiled<EPI_BIAS, A_ROWMAJOR>(a, stream);
         case EPI_BIAS_GELU: return launch_tiled<EPI_BIAS_GELU, A_ROWMAJOR>(a, stream);

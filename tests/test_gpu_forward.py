@@ -85,8 +85,8 @@ def test_large_512_long_sequence_vs_golden(golden_dir):
 def test_base_bs64_properties():
     """BASELINE config 2 at full size.  The oracle would need minutes here, so use what the arithmetic guarantees:
     rows of different images never mix and the k-order of every dot product is fixed, hence
-    (1) image i of a 64-batch gives BIT-IDENTICAL taps to the same image run in a batch of 2 (which the previous test
-        pins to the oracle and to HF), (2) a permutation of the batch permutes the outputs bit-exactly,
+    (1) image i of a 64-batch gives BIT-IDENTICAL taps to the same image run in a batch of 2, 1 or 5 (the batch of 2 is
+        what the previous test pins to the oracle and to HF; 1 and 2 take the serving-size GEMM tiling), (2) a permutation of the batch permutes the outputs bit-exactly,
     (3) repeated runs are bit-identical (no atomics, no race)."""
     cfg = cfgs.vit_base()
     m, _ = _model(cfg, 0)
@@ -98,6 +98,12 @@ def test_base_bs64_properties():
     pair = [h.cpu().numpy() for h in _run(m, x[[37, 5]]).hidden_states if h is not None]
     for a, b in zip(big, pair):
         np.testing.assert_array_equal(a[[37, 5]], b)
+    # serving sizes run the 32x32 / 16x16x4 GEMM tiling (gemm_thin_f32.hip) and the query-split attention launch: one
+    # image alone (M = 197) and five (M = 985, back on the big tilings) still reproduce their rows of the 64-batch
+    for sel in ([11], [3, 60, 17, 41, 8]):
+        few = [h.cpu().numpy() for h in _run(m, x[sel]).hidden_states if h is not None]
+        for a, b in zip(big, few):
+            np.testing.assert_array_equal(a[sel], b)
     again = [h.cpu().numpy() for h in _run(m, x).hidden_states if h is not None]
     for a, b in zip(big, again):
         np.testing.assert_array_equal(a, b)
