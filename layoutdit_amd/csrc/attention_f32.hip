@@ -18,6 +18,15 @@
 //   * O^T leaves each lane with 4 consecutive d per register quad -> 16-B stores.
 #include "ldit_common.h"
 
+#ifdef LDIT_GEMM_STAMPS
+// diagnostic build only (make dbg; scripts/attn_f32_stamps.py): per-workgroup phase cycles of wave 0, written to a buffer
+// registered by ldit_dbg_set_attn32_stamps - 6 x int64 per workgroup: Q load + staging, S = K Q^T, softmax, P V, store, total
+__device__ unsigned long long *g_attn32_stamps = nullptr;
+#define A32_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define A32_STAMP(var)
+#endif
+
 namespace ldit {
 
 namespace {
@@ -25,8 +34,10 @@ namespace {
 constexpr int KSTR = 68;   // floats per K row in LDS (64 + 4 pad: 272-B stride -> 16 lanes hit 16 distinct 16-B slots)
 constexpr int VSTR = 64;
 
+// (NW = 4 is held to the 256 registers of NW = 8: given 512, hipcc parks every V fragment read right in front of its MFMA
+// and the P V phase ran 2.7x longer - 42.8k vs 15.9k cycles per wave.)
 template <int KT, int NW>
-__global__ void __launch_bounds__(NW * 64, NW / 4) attention_f32(const float *__restrict__ Q, const float *__restrict__ K,
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : NW / 4) attention_f32(const float *__restrict__ Q, const float *__restrict__ K,
                                                      const float *__restrict__ V, float *__restrict__ O, int N, int H,
                                                      int ldq, int ldk, int ldv, int ldo, float scale, int nqg)
 {
@@ -43,6 +54,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attention_f32(const float *__
     const int qt = qg * NW + wave;
     const bool active = qt * 32 < N;          // wave-uniform
     const size_t tok0 = (size_t)b * N;
+#ifdef LDIT_GEMM_STAMPS
+    unsigned long long ph[4] = {0, 0, 0, 0};
+#endif
+    A32_STAMP(t_begin);
 
     // Q^T operand: lane (query li, half lh) keeps Q[query][32*lh .. 32*lh+31]; MFMA step s pairs d = {s, 32+s}
     float q[32];
@@ -65,20 +80,43 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attention_f32(const float *__
     for (int c0 = 0; c0 < N; c0 += KROWS) {
         const int nkeys = (N - c0) < KROWS ? (N - c0) : KROWS;
         const int ktiles = (nkeys + 31) >> 5;                    // wave- and block-uniform
+        A32_STAMP(t0);
         if (c0) __syncthreads();                                 // previous chunk fully consumed
         // ---- stage K, V chunk (zero-fill keys >= N inside the last tile: 0 * garbage must not make NaN) ---------
-        for (int u = tid; u < ktiles * 32 * 16; u += NW * 64) {
-            const int row = u >> 4, c4 = (u & 15) * 4;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (row < nkeys) {
-                kv = *reinterpret_cast<const f32x4 *>(K + (tok0 + c0 + row) * ldk + head * 64 + c4);
-                vv = *reinterpret_cast<const f32x4 *>(V + (tok0 + c0 + row) * ldv + head * 64 + c4);
-            }
-            *reinterpret_cast<f32x4 *>(Ks + row * KSTR + c4) = kv;
-            *reinterpret_cast<f32x4 *>(Vs + row * VSTR + c4) = vv;
+        // A batch of a thread's loads is issued before its first LDS store (two to four memory round trips per chunk, not one
+        // per element: the rolled loop paid ~0.8 us for each of its 7-14 trips, a third of the kernel at small batches).
+        {
+            constexpr int PER = (32 * 16) / (NW * 64) > 0 ? (32 * 16) / (NW * 64) : 1;     // float4 per thread, key tile and operand
+            static_assert((32 * 16) % (NW * 64) == 0, "a key tile must split evenly over the threads");
+            constexpr int BATCH = 4;                   // key tiles per pass: 4 + 4 loads in flight (32 registers)
+#pragma unroll
+            for (int e = 0; e < PER; ++e)
+#pragma unroll
+                for (int k0 = 0; k0 < KT; k0 += BATCH) {
+                    f32x4 kv[BATCH], vv[BATCH];
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i) {
+                        const int kt = k0 + i, u = kt * 512 + e * NW * 64 + tid, row = u >> 4, c4 = (u & 15) * 4;
+                        kv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        vv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (kt < KT && kt < ktiles && row < nkeys) {
+                            kv[i] = *reinterpret_cast<const f32x4 *>(K + (tok0 + c0 + row) * ldk + head * 64 + c4);
+                            vv[i] = *reinterpret_cast<const f32x4 *>(V + (tok0 + c0 + row) * ldv + head * 64 + c4);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < BATCH; ++i) {
+                        const int kt = k0 + i, u = kt * 512 + e * NW * 64 + tid, row = u >> 4, c4 = (u & 15) * 4;
+                        if (kt < KT && kt < ktiles) {
+                            *reinterpret_cast<f32x4 *>(Ks + row * KSTR + c4) = kv[i];
+                            *reinterpret_cast<f32x4 *>(Vs + row * VSTR + c4) = vv[i];
+                        }
+                    }
+                }
         }
         __syncthreads();
         if (!active) continue;
+        A32_STAMP(t1);
 
         // ---- S^T = K . Q^T --------------------------------------------------------------------------------------
         f32x16 s[KT];
@@ -97,6 +135,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attention_f32(const float *__
                 }
             }
         }
+#ifdef LDIT_GEMM_STAMPS
+        asm volatile("s_nop 0" ::"v"(s[0][0]), "v"(s[KT - 1][0]));
+#endif
+        A32_STAMP(t2);
         // ---- scale, mask the padded keys, chunk max ---------------------------------------------------------------
         float mx = -INFINITY;
 #pragma unroll
@@ -133,6 +175,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attention_f32(const float *__
 #pragma unroll
             for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
         }
+        A32_STAMP(t3);
         // ---- O^T += V^T . P^T ---------------------------------------------------------------------------------------
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
@@ -149,9 +192,19 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) attention_f32(const float *__
                 }
             }
         }
+#ifdef LDIT_GEMM_STAMPS
+        asm volatile("s_nop 0" ::"v"(o[0][0]), "v"(o[1][0]));
+        ph[0] += t1 - t0 + (c0 ? 0 : t0 - t_begin); ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += __builtin_amdgcn_s_memtime() - t3;
+#endif
     }
 
     if (!active) return;
+#ifdef LDIT_GEMM_STAMPS
+    if (g_attn32_stamps && wave == 0 && lane == 0) {
+        unsigned long long *d = g_attn32_stamps + (size_t)blockIdx.x * 6;
+        d[0] = ph[0]; d[1] = ph[1]; d[2] = ph[2]; d[3] = ph[3]; d[5] = __builtin_amdgcn_s_memtime() - t_begin;
+    }
+#endif
     const float l = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l;
     const int qrow = qt * 32 + li;
@@ -203,3 +256,11 @@ int launch_attention(const float *Q, const float *K, const float *V, float *O, i
 }
 
 }  // namespace ldit
+
+#ifdef LDIT_GEMM_STAMPS
+extern "C" int ldit_dbg_set_attn32_stamps(void *buf)
+{
+    unsigned long long *p = static_cast<unsigned long long *>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn32_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -16,7 +16,10 @@
 //     fragments of tile kt+1 are read between tile kt's MFMAs; fragment reads are inline asm (the compiler cannot tell they
 //     do not alias the DMA writes of later slots and would drain vmcnt to zero in front of each).
 //   * fragment = ds_read_b128 of 16-B chunk 2c + (q & 1) of the XOR-swizzled 128-B row (lane = row r = lane & 15, quarter
-//     q = lane >> 4); the lane keeps dwords (q >> 1) and (q >> 1) + 2 - its k of MFMA 1 and MFMA 2 of chunk c.
+//     q = lane >> 4): the 16 lanes of a quarter read 16 different rows, conflict-free (a ds_read2_b32 of just the two dwords
+//     a lane needs costs twice the LDS cycles - a 32-lane half only reaches 16 banks - and LDS issue, not the MFMA chain,
+//     then sets the pace).  The lane keeps dwords (q >> 1) and (q >> 1) + 2 - its k of MFMA 1 and MFMA 2 of chunk c - with
+//     one select per MFMA operand.
 //   * blockIdx -> tile: column tiles are dealt round-robin to the XCDs and the row tiles of one column tile are
 //     consecutive on that XCD, so a weight row is fetched from HBM into ONE L2, once.
 #include <cstdlib>
@@ -96,55 +99,53 @@ __global__ void __launch_bounds__(256) gemm_thin_f32(const GemmArgs p, const int
     const bool live = (m0 + wm * 16 < p.M) && (n0 + wn * 16 < p.N);          // wave-uniform: a 16x16 tile wholly outside idles
 
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    // Fragments of k-tile kt (half kt & 1 of stage kt / 2): one ds_read_b128 per operand and 8-deep chunk - the 16 lanes
-    // of a quarter read 16 different rows, conflict-free under the row swizzle (ds_read2_b32 of just the two dwords a lane
-    // needs costs twice the LDS cycles: a 32-lane half only reaches 16 banks, and LDS issue, not the MFMA chain, then sets
-    // the pace).  The lane keeps its k pair of the chunk - dwords (0,2), or (1,3) in the upper two quarters - with one
-    // v_cndmask per MFMA operand.
+    // fragments of k-tile kt live in half kt & 1 of slot (kt / 2) % NS
     struct Raw { f32x4 a[4], b[4]; };
-    struct Ops { float a0[4], a1[4], b0[4], b1[4]; };
+    struct Op4 { float a0, a1, b0, b1; };              // operands of the two MFMAs of one chunk
     const bool odd = (q >> 1) != 0;
     auto read_chunk = [&](int kt, int c, Raw &f) {
         const unsigned base = lds0 + (unsigned)(((kt >> 1) % NS) * STAGE + (kt & 1) * HALF);
         asm volatile("ds_read_b128 %0, %1" : "=v"(f.a[c]) : "v"(base + fa[c]));
         asm volatile("ds_read_b128 %0, %1" : "=v"(f.b[c]) : "v"(base + fb[c]));
     };
-    // The selects run when the fragments LAND, a whole barrier ahead of the MFMAs that consume them, and a sched_barrier
-    // keeps them there.  Left next to their MFMA (v_cndmask, v_cndmask, one instruction, v_mfma) the MFMA read the OLD
-    // value of the register written second: on gfx950 a VALU result is not yet visible to an MFMA issued one wait state
-    // later, and hipcc's hazard recognizer does not separate them (measured: products a[k=8] b[k=2]; two wait states are
-    // enough).
     const unsigned oddm = odd ? 0xffffffffu : 0u;
-    auto pick = [&](float even_v, float odd_v) {      // v_bfi_b32: one instruction, and no select for hipcc to re-index
+    auto pick = [&](float even_v, float odd_v) {      // one instruction, and no select for hipcc to re-index as v[odd]
         return __uint_as_float((__float_as_uint(odd_v) & oddm) | (__float_as_uint(even_v) & ~oddm));
     };
-    auto select = [&](const Raw &f, Ops &o) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            o.a0[c] = pick(f.a[c][0], f.a[c][1]); o.a1[c] = pick(f.a[c][2], f.a[c][3]);
-            o.b0[c] = pick(f.b[c][0], f.b[c][1]); o.b1[c] = pick(f.b[c][2], f.b[c][3]);
-        }
-        // pinned HERE: a volatile asm that "rewrites" the sixteen operands can neither sink towards the MFMAs nor be
-        // duplicated into the next tile's block
-        asm volatile("" : "+v"(o.a0[0]), "+v"(o.a0[1]), "+v"(o.a0[2]), "+v"(o.a0[3]), "+v"(o.a1[0]), "+v"(o.a1[1]), "+v"(o.a1[2]),
-                          "+v"(o.a1[3]), "+v"(o.b0[0]), "+v"(o.b0[1]), "+v"(o.b0[2]), "+v"(o.b0[3]), "+v"(o.b1[0]), "+v"(o.b1[1]),
-                          "+v"(o.b1[2]), "+v"(o.b1[3]));
+    auto select = [&](const Raw &f, int c) {
+        return Op4{pick(f.a[c][0], f.a[c][1]), pick(f.a[c][2], f.a[c][3]), pick(f.b[c][0], f.b[c][1]), pick(f.b[c][2], f.b[c][3])};
     };
-    // One k-tile: its operands are in registers already; the reads of the NEXT k-tile are dealt out between this tile's
-    // MFMA pairs (a wave that issues eight LDS reads back to back stalls at issue behind the other waves' reads and starts
-    // its chain late), waited for at the end and reduced to the next tile's operands.
-    auto tile = [&](int kt, const Ops &cur, Raw &raw, Ops &nxt) {
+    // One k-tile, four groups pinned by sched_barriers:  [LDS reads of the next tile | selects of the NEXT chunk] [two MFMAs].
+    //   * the reads of tile kt+1 go out in the first two groups (a wave that issues eight reads back to back stalls at issue
+    //     behind the other waves' reads and starts its chain late; left to the end they are waited for in the open);
+    //   * a chunk's four selects run two MFMAs ahead of the MFMAs that consume them, never next to them: written as
+    //     v_cndmask, v_cndmask, one instruction, v_mfma the MFMA read the OLD value of the register written second - on
+    //     gfx950 a VALU result is not yet visible to an MFMA issued one wait state later and hipcc's hazard recognizer does
+    //     not always separate them (measured: products a[k=8] b[k=2]; two wait states are enough).  A select is a pure
+    //     value that no sched_barrier holds in place - each group's results pass through a volatile asm, which does.
+    //     Chunk 0's operands are selected at the end of the previous tile.
+    auto tile = [&](int kt, const Raw &cur, Op4 &o, Raw &nxt) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            read_chunk(kt + 1, c, raw);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a0[c], cur.b0[c], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a1[c], cur.b1[c], acc, 0, 0, 0);
+            if (c < 2) {
+                read_chunk(kt + 1, 2 * c, nxt);
+                read_chunk(kt + 1, 2 * c + 1, nxt);
+            }
+            Op4 n = o;
+            if (c < 3) {
+                n = select(cur, c + 1);
+                asm volatile("" : "+v"(n.a0), "+v"(n.a1), "+v"(n.b0), "+v"(n.b1));      // pinned in front of this group's MFMAs
+            }
             __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0, o.b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1, o.b1, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            o = n;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        select(raw, nxt);
-        __builtin_amdgcn_sched_barrier(0);
+        o = select(nxt, 0);
+        asm volatile("" : "+v"(o.a0), "+v"(o.a1), "+v"(o.b0), "+v"(o.b1));
     };
     // Ring protocol, per stage j: in front of the wait the wave has stages j+1 .. j+NS-2 in flight, four loads each; stage
     // j+1 is the oldest, so it has landed once at most 4(NS-3) are pending, and behind the barrier every wave's pieces of it
@@ -153,18 +154,18 @@ __global__ void __launch_bounds__(256) gemm_thin_f32(const GemmArgs p, const int
     // into the idle slot so the count stays exact (nobody reads it).
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) issue(s);
-    Raw raw;
-    Ops o0, o1;
+    Raw r0, r1;
+    Op4 o;
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (live) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) read_chunk(0, c, raw);
+        for (int c = 0; c < 4; ++c) read_chunk(0, c, r0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        select(raw, o0);
-        __builtin_amdgcn_sched_barrier(0);
+        o = select(r0, 0);
+        asm volatile("" : "+v"(o.a0), "+v"(o.a1), "+v"(o.b0), "+v"(o.b1));
     }
 #ifdef LDIT_GEMM_STAMPS
     st_clk1 = __builtin_amdgcn_s_memtime();
@@ -175,8 +176,8 @@ __global__ void __launch_bounds__(256) gemm_thin_f32(const GemmArgs p, const int
         asm volatile("" ::: "memory");
         issue(j + NS - 1);
         if (live) {
-            tile(2 * j, o0, raw, o1);
-            if (2 * j + 1 < nk) tile(2 * j + 1, o1, raw, o0);
+            tile(2 * j, r0, o, r1);
+            if (2 * j + 1 < nk) tile(2 * j + 1, r1, o, r0);
         }
     }
 #ifdef LDIT_GEMM_STAMPS
