@@ -23,6 +23,7 @@
 //   * blockIdx -> tile: column tiles are dealt round-robin to the XCDs and the row tiles of one column tile are
 //     consecutive on that XCD, so a weight row is fetched from HBM into ONE L2, once.
 #include <cstdlib>
+#include <type_traits>
 
 #include "ldit_common.h"
 
@@ -99,87 +100,97 @@ __global__ void __launch_bounds__(256) gemm_thin_f32(const GemmArgs p, const int
     const bool live = (m0 + wm * 16 < p.M) && (n0 + wn * 16 < p.N);          // wave-uniform: a 16x16 tile wholly outside idles
 
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    // fragments of k-tile kt live in half kt & 1 of slot (kt / 2) % NS
+    // Fragments of k-tile kt live in half kt & 1 of slot (kt / 2) % NS.  The stage loop is unrolled over the ring, so a
+    // tile's slot and half are compile-time constants and every fragment read is ds_read_b128 with an immediate offset from
+    // eight lane-constant addresses (no address arithmetic inside the chain).
     struct Raw { f32x4 a[4], b[4]; };
-    struct Op4 { float a0, a1, b0, b1; };              // operands of the two MFMAs of one chunk
-    const bool odd = (q >> 1) != 0;
-    auto read_chunk = [&](int kt, int c, Raw &f) {
-        const unsigned base = lds0 + (unsigned)(((kt >> 1) % NS) * STAGE + (kt & 1) * HALF);
-        asm volatile("ds_read_b128 %0, %1" : "=v"(f.a[c]) : "v"(base + fa[c]));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(f.b[c]) : "v"(base + fb[c]));
-    };
-    const unsigned oddm = odd ? 0xffffffffu : 0u;
+    struct Op2 { float a, b; };                        // the operands of one MFMA
+    unsigned fav[4], fbv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { fav[c] = lds0 + fa[c]; fbv[c] = lds0 + fb[c]; }
+    const unsigned oddm = (q >> 1) ? 0xffffffffu : 0u;
     auto pick = [&](float even_v, float odd_v) {      // one instruction, and no select for hipcc to re-index as v[odd]
         return __uint_as_float((__float_as_uint(odd_v) & oddm) | (__float_as_uint(even_v) & ~oddm));
     };
-    auto select = [&](const Raw &f, int c) {
-        return Op4{pick(f.a[c][0], f.a[c][1]), pick(f.a[c][2], f.a[c][3]), pick(f.b[c][0], f.b[c][1]), pick(f.b[c][2], f.b[c][3])};
-    };
-    // One k-tile, four groups pinned by sched_barriers:  [LDS reads of the next tile | selects of the NEXT chunk] [two MFMAs].
-    //   * the reads of tile kt+1 go out in the first two groups (a wave that issues eight reads back to back stalls at issue
-    //     behind the other waves' reads and starts its chain late; left to the end they are waited for in the open);
-    //   * a chunk's four selects run two MFMAs ahead of the MFMAs that consume them, never next to them: written as
-    //     v_cndmask, v_cndmask, one instruction, v_mfma the MFMA read the OLD value of the register written second - on
-    //     gfx950 a VALU result is not yet visible to an MFMA issued one wait state later and hipcc's hazard recognizer does
-    //     not always separate them (measured: products a[k=8] b[k=2]; two wait states are enough).  A select is a pure
-    //     value that no sched_barrier holds in place - each group's results pass through a volatile asm, which does.
-    //     Chunk 0's operands are selected at the end of the previous tile.
-    auto tile = [&](int kt, const Raw &cur, Op4 &o, Raw &nxt) {
+    // One k-tile = a chain of eight dependent MFMAs (33 cycles each, nothing else to overlap them with), so everything
+    // else is dealt out into their shadows, three instructions behind each MFMA m:
+    //   * read #m of the NEXT tile's eight fragments (chunk m/2, A for even m, B for odd);
+    //   * the two selects that make MFMA m+2's operands: a lane keeps dwords (0,2) of a chunk, or (1,3) in the upper two
+    //     quarters.  They sit two MFMAs ahead of their consumer, never next to it: written as v_cndmask, v_cndmask, one
+    //     instruction, v_mfma the MFMA read the OLD value of the register written second - on gfx950 a VALU result is not
+    //     yet visible to an MFMA issued one wait state later, and hipcc's hazard recognizer does not always separate them
+    //     (measured: products a[k=8] b[k=2]).  A select is a pure value that no sched_barrier holds in place: each pair
+    //     passes through a volatile asm, which does.
+    //   * behind every even m a COUNTED lgkmcnt(5): LDS returns in order, and of the reads in flight only the five youngest
+    //     may still be pending when chunk (m+2)/2 of this tile (or chunk 0 of the next, for m = 6) is selected from.
+    // With the selects and four v_add per chunk next to the MFMAs the same loop ran 630 cycles per k-tile against the
+    // chain's 266: in a dependent chain every instruction between two MFMAs is on the critical path.
+    auto tile = [&](auto tc, const Raw &cur, Raw &nxt, Op2(&op)[2]) {
+        constexpr int NT = (decltype(tc)::value + 1) & (2 * NS - 1);              // ring position of the next tile
+        constexpr int OFF = (NT >> 1) * STAGE + (NT & 1) * HALF;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c < 2) {
-                read_chunk(kt + 1, 2 * c, nxt);
-                read_chunk(kt + 1, 2 * c + 1, nxt);
-            }
-            Op4 n = o;
-            if (c < 3) {
-                n = select(cur, c + 1);
-                asm volatile("" : "+v"(n.a0), "+v"(n.a1), "+v"(n.b0), "+v"(n.b1));      // pinned in front of this group's MFMAs
-            }
+        for (int m = 0; m < 8; ++m) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(op[m & 1].a, op[m & 1].b, acc, 0, 0, 0);
+            if (m & 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(nxt.b[m >> 1]) : "v"(fbv[m >> 1]), "n"(OFF));
+            else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(nxt.a[m >> 1]) : "v"(fav[m >> 1]), "n"(OFF));
+            if (!(m & 1)) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+            const int m2 = m + 2, c2 = (m2 & 7) >> 1, e = (m2 & 1) * 2;
+            const Raw &src = m2 < 8 ? cur : nxt;
+            Op2 n{pick(src.a[c2][e], src.a[c2][e + 1]), pick(src.b[c2][e], src.b[c2][e + 1])};
+            asm volatile("" : "+v"(n.a), "+v"(n.b));
+            op[m & 1] = n;
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a0, o.b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a1, o.b1, acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            o = n;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        o = select(nxt, 0);
-        asm volatile("" : "+v"(o.a0), "+v"(o.a1), "+v"(o.b0), "+v"(o.b1));
     };
-    // Ring protocol, per stage j: in front of the wait the wave has stages j+1 .. j+NS-2 in flight, four loads each; stage
-    // j+1 is the oldest, so it has landed once at most 4(NS-3) are pending, and behind the barrier every wave's pieces of it
-    // have - which the fragment prefetch of its first k-tile (during stage j's second) needs.  Behind the same barrier all
-    // waves are done reading stage j-1, which is refilled with stage j+NS-1.  Past the end the last stage is re-fetched
-    // into the idle slot so the count stays exact (nobody reads it).
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue(s);
+    // Ring protocol, per stage j (slot j % NS): in front of the wait the wave has stages j+1 .. j+NS-2 in flight, four loads
+    // each; stage j+1 is the oldest, so it has landed once at most 4(NS-3) are pending, and behind the barrier every wave's
+    // pieces of it have - which the fragment reads of its first k-tile (during stage j's second) need.  Behind the same
+    // barrier all waves are done reading stage j-1, which is refilled with stage j+NS-1.  Past the end the last stage is
+    // re-fetched into the idle slot so the count stays exact (nobody reads it).
     Raw r0, r1;
-    Op4 o;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (live) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) read_chunk(0, c, r0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        o = select(r0, 0);
-        asm volatile("" : "+v"(o.a0), "+v"(o.a1), "+v"(o.b0), "+v"(o.b1));
-    }
-#ifdef LDIT_GEMM_STAMPS
-    st_clk1 = __builtin_amdgcn_s_memtime();
-#endif
-    for (int j = 0; j < nst; ++j) {
+    Op2 op[2];
+    auto stage = [&](auto sc, int j) {
+        constexpr int S = decltype(sc)::value;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 3)) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         issue(j + NS - 1);
         if (live) {
-            tile(2 * j, r0, o, r1);
-            if (2 * j + 1 < nk) tile(2 * j + 1, r1, o, r0);
+            tile(std::integral_constant<int, 2 * S>{}, r0, r1, op);
+            if (2 * j + 1 < nk) tile(std::integral_constant<int, 2 * S + 1>{}, r1, r0, op);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(r0.a[c]) : "v"(fav[c]));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(r0.b[c]) : "v"(fbv[c]));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            op[i] = Op2{pick(r0.a[0][2 * i], r0.a[0][2 * i + 1]), pick(r0.b[0][2 * i], r0.b[0][2 * i + 1])};
+            asm volatile("" : "+v"(op[i].a), "+v"(op[i].b));
         }
     }
+#ifdef LDIT_GEMM_STAMPS
+    st_clk1 = __builtin_amdgcn_s_memtime();
+#endif
+    static_assert(NS == 4, "the stage loop below is unrolled over a four-slot ring");
+    for (int j0 = 0; j0 < nst; j0 += NS) {
+        stage(std::integral_constant<int, 0>{}, j0);
+        if (j0 + 1 < nst) stage(std::integral_constant<int, 1>{}, j0 + 1);
+        if (j0 + 2 < nst) stage(std::integral_constant<int, 2>{}, j0 + 2);
+        if (j0 + 3 < nst) stage(std::integral_constant<int, 3>{}, j0 + 3);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the fragment reads issued for a tile past the end: retire them
+    __builtin_amdgcn_sched_barrier(0);
 #ifdef LDIT_GEMM_STAMPS
     st_clk2 = __builtin_amdgcn_s_memtime();
 #endif
