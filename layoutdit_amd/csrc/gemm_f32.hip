@@ -398,7 +398,7 @@ int launch_gemm(const GemmArgs &a, int epi, int amode, hipStream_t stream)
     // LDIT_GEMM_TILE=4 forces it for any M, 0..3 force one of the big tilings (tests cover every instantiation that way).
     {
         const char *force = getenv("LDIT_GEMM_TILE");
-        const bool thin = force ? (force[0] == '4' && force[1] == 0) : a.M <= gemm_thin_max_rows();
+        const bool thin = force ? (force[0] == '4' && force[1] == 0) : gemm_thin_prefers(a.M, a.N);
         if (thin && epi >= EPI_BIAS && epi <= EPI_SCALE_RESID) {
             if (epi == EPI_SCALE_RESID && (!a.lam || !a.R)) return fail(LDIT_EINVAL, "gemm: scale+residual epilogue needs lam and R");
             return launch_gemm_thin(a, epi, stream);

@@ -258,12 +258,15 @@ int launch_thin(const GemmArgs &a, hipStream_t stream)
 
 }  // namespace
 
-// rows up to which launch_gemm prefers this kernel (LDIT_GEMM_THIN_MAXM overrides; 0 switches it off - the tests compare
-// the two paths bit for bit that way)
-int gemm_thin_max_rows()
+// launch_gemm prefers this kernel while the 64 x 64 tiling would be at most this many workgroups (under one round of the
+// chip with room to spare): measured on cold weights, M = 197..788 x N = 768 and M = 197 x N = 2304/3072 run 1.2-1.9x faster
+// here, M = 394 x N = 2304 (252 tiles) and beyond run faster on the big tilings.  LDIT_GEMM_THIN_TILES overrides; 0
+// switches the kernel off.
+bool gemm_thin_prefers(int M, int N)
 {
-    if (const char *e = getenv("LDIT_GEMM_THIN_MAXM")) return atoi(e);
-    return 512;
+    long limit = 192;
+    if (const char *e = getenv("LDIT_GEMM_THIN_TILES")) limit = atol(e);
+    return (long)((M + 63) / 64) * ((N + 63) / 64) <= limit;
 }
 
 // Row-major A, bias / bias+GELU / LayerScale+residual epilogues; operands were validated by launch_gemm.

@@ -149,7 +149,7 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs &a, int epi, int amode, hipStream_t stream);
 int launch_gemm_panel(const GemmArgs &a, int epi, int amode, hipStream_t stream);   // 304 x 128 panel tiling (gemm_panel_f32.hip)
 int launch_gemm_thin(const GemmArgs &a, int epi, hipStream_t stream);               // serving-size M (gemm_thin_f32.hip)
-int gemm_thin_max_rows();
+bool gemm_thin_prefers(int M, int N);
 
 // ---- other kernels ---------------------------------------------------------------------------------------------
 int launch_layernorm(const float *X, const float *g, const float *b, float *Y, int64_t rows, int C, float eps,

@@ -98,8 +98,9 @@ def test_base_bs64_properties():
     pair = [h.cpu().numpy() for h in _run(m, x[[37, 5]]).hidden_states if h is not None]
     for a, b in zip(big, pair):
         np.testing.assert_array_equal(a[[37, 5]], b)
-    # serving sizes run the 32x32 / 16x16x4 GEMM tiling (gemm_thin_f32.hip) and the query-split attention launch: one
-    # image alone (M = 197) and five (M = 985, back on the big tilings) still reproduce their rows of the 64-batch
+    # serving sizes run the 32x32 / 16x16x4 GEMM tiling (gemm_thin_f32.hip: all four GEMMs at one image, o_proj and fc2 up to
+    # four) and the query-split attention launch (up to ten images): one image alone and five still reproduce their rows of
+    # the 64-batch
     for sel in ([11], [3, 60, 17, 41, 8]):
         few = [h.cpu().numpy() for h in _run(m, x[sel]).hidden_states if h is not None]
         for a, b in zip(big, few):
