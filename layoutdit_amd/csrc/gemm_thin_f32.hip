@@ -116,11 +116,12 @@ __global__ void __launch_bounds__(256) gemm_thin_f32(const GemmArgs p, const int
     // else is dealt out into their shadows, three instructions behind each MFMA m:
     //   * read #m of the NEXT tile's eight fragments (chunk m/2, A for even m, B for odd);
     //   * the two selects that make MFMA m+2's operands: a lane keeps dwords (0,2) of a chunk, or (1,3) in the upper two
-    //     quarters.  They sit two MFMAs ahead of their consumer, never next to it: written as v_cndmask, v_cndmask, one
-    //     instruction, v_mfma the MFMA read the OLD value of the register written second - on gfx950 a VALU result is not
-    //     yet visible to an MFMA issued one wait state later, and hipcc's hazard recognizer does not always separate them
-    //     (measured: products a[k=8] b[k=2]).  A select is a pure value that no sched_barrier holds in place: each pair
-    //     passes through a volatile asm, which does.
+    //     quarters.  They are plain C++ (hipcc emits v_cndmask) and sit two MFMAs ahead of their consumer.  NOT inline asm:
+    //     on gfx950 a VALU result is not yet visible to an MFMA issued one wait state later; hipcc separates its own VALU
+    //     from a dependent MFMA with s_nop 1, but an asm-written v_cndmask is invisible to its hazard recognizer - the
+    //     sequence v_cndmask, v_cndmask, one instruction, v_mfma made the MFMA read the OLD value of the register written
+    //     second (measured: products a[k=8] b[k=2]).  A select is a pure value that no sched_barrier holds in place: each
+    //     pair passes through an empty volatile asm, which pins it without hiding the producer.
     //   * behind every even m a COUNTED lgkmcnt(5): LDS returns in order, and of the reads in flight only the five youngest
     //     may still be pending when chunk (m+2)/2 of this tile (or chunk 0 of the next, for m = 6) is selected from.
     // With the selects and four v_add per chunk next to the MFMAs the same loop ran 630 cycles per k-tile against the
