@@ -339,20 +339,26 @@ int launch_tiled(const GemmArgs &a, hipStream_t stream)
     // main loss at M = B*197, and small tiles pay more LDS/L2 traffic per FLOP.  LDIT_GEMM_TILE=0|1|2|3 forces one
     // (tests use it to cover every instantiation).
     struct Cand { int bm, bn, id; double eff; };
-    const Cand cands[4] = {{304, 128, 3, 1.0}, {320, 128, 0, 1.0}, {128, 128, 1, 0.9}, {64, 64, 2, 0.6}};
+    // ids 5-7: shorter panels of the same kernel (144 / 80 / 48 rows) for the mid-size batches, priced with a fixed cost of
+    // ~24 rows per tile (the 128 weight rows are staged whatever the height)
+    const Cand cands[7] = {{304, 128, 3, 1.0}, {320, 128, 0, 1.0}, {128, 128, 1, 0.9}, {64, 64, 2, 0.6},
+                           {144, 128, 5, 144.0 / 168.0}, {80, 128, 6, 80.0 / 104.0}, {48, 128, 7, 48.0 / 72.0}};
     double best = -1.0;
     int pick = 2;
     for (const Cand &c : cands) {
+        if (c.id >= 5 && (AMODE != A_ROWMAJOR || EPI == EPI_EMBED)) continue;
         const long tiles = (long)((a.M + c.bm - 1) / c.bm) * ((a.N + c.bn - 1) / c.bn);
         const long rounds = (tiles + 255) / 256;
         const double cost = (double)rounds * c.bm * c.bn / c.eff;
         if (best < 0 || cost < best) { best = cost; pick = c.id; }
     }
     if (const char *force = getenv("LDIT_GEMM_TILE")) {
-        if (force[0] >= '0' && force[0] <= '3' && force[1] == 0) pick = force[0] - '0';
+        if (force[0] >= '0' && force[0] <= '7' && force[0] != '4' && force[1] == 0) pick = force[0] - '0';
     }
+    if ((AMODE != A_ROWMAJOR || EPI == EPI_EMBED) && pick >= 5) pick = 3;
     if (AMODE == A_CONV3 && pick == 3) pick = 0;                      // the panel kernel has no implicit-im2col loader
     if (pick == 3) return launch_gemm_panel(a, EPI, AMODE, stream);   // 304 x 128 panel tiling (gemm_panel_f32.hip)
+    if (pick >= 5) return launch_gemm_panel(a, EPI, AMODE, stream, pick == 5 ? 144 : pick == 6 ? 80 : 48);
     switch (pick) {
         case 0: return launch_one<5, 2, EPI, AMODE>(a, stream);
         case 1: return launch_one<2, 2, EPI, AMODE>(a, stream);
@@ -395,7 +401,7 @@ int launch_gemm(const GemmArgs &a, int epi, int amode, hipStream_t stream)
         return launch_tiled<EPI_EMBED, A_PATCH>(a, stream);
     }
     // serving-size batches: the 32 x 32 / 16x16x4 kernel (same k order, bit-identical results; gemm_thin_f32.hip).
-    // LDIT_GEMM_TILE=4 forces it for any M, 0..3 force one of the big tilings (tests cover every instantiation that way).
+    // LDIT_GEMM_TILE=4 forces it for any M, 0..3 and 5..7 force one of the big tilings (tests cover every instantiation that way).
     {
         const char *force = getenv("LDIT_GEMM_TILE");
         const bool thin = force ? (force[0] == '4' && force[1] == 0) : gemm_thin_prefers(a.M, a.N);

@@ -440,14 +440,28 @@ int launch_panel_v(const GemmArgs &a, hipStream_t stream)
 
 }  // namespace
 
-// Panel tiling with a 304 x 128 block.  Arguments already validated by launch_gemm.
-int launch_gemm_panel(const GemmArgs &a, int epi, int amode, hipStream_t stream)
+// Panel tiling with a (32 T + 16) x 128 block: 304 rows for the headline shapes, 144 / 80 / 48 rows where the taller panels
+// would leave most of the chip idle (M = 1 576 .. 3 152 rows at N = 768: 36-66 panels of 304 against 240-198 of 80 / 48).
+// Every height keeps the 32-row tiles + 16-row remainder structure, so a row's product order - and its bits - do not depend on
+// the height.  Arguments already validated by launch_gemm.
+template <int T32>
+static int launch_panel_epi(const GemmArgs &a, int epi, hipStream_t stream)
+{
+    switch (epi) {
+        case EPI_BIAS: return launch_panel<T32, true, EPI_BIAS, A_ROWMAJOR>(a, stream);
+        case EPI_BIAS_GELU: return launch_panel<T32, true, EPI_BIAS_GELU, A_ROWMAJOR>(a, stream);
+        default: return launch_panel<T32, true, EPI_SCALE_RESID, A_ROWMAJOR>(a, stream);
+    }
+}
+
+int launch_gemm_panel(const GemmArgs &a, int epi, int amode, hipStream_t stream, int height)
 {
     if (amode == A_PATCH) return launch_panel<9, true, EPI_EMBED, A_PATCH>(a, stream);
-    switch (epi) {
-        case EPI_BIAS: return launch_panel<9, true, EPI_BIAS, A_ROWMAJOR>(a, stream);
-        case EPI_BIAS_GELU: return launch_panel<9, true, EPI_BIAS_GELU, A_ROWMAJOR>(a, stream);
-        default: return launch_panel<9, true, EPI_SCALE_RESID, A_ROWMAJOR>(a, stream);
+    switch (height) {
+        case 48: return launch_panel_epi<1>(a, epi, stream);
+        case 80: return launch_panel_epi<2>(a, epi, stream);
+        case 144: return launch_panel_epi<4>(a, epi, stream);
+        default: return launch_panel_epi<9>(a, epi, stream);
     }
 }
 

@@ -147,7 +147,7 @@ struct GemmArgs {
 };
 
 int launch_gemm(const GemmArgs &a, int epi, int amode, hipStream_t stream);
-int launch_gemm_panel(const GemmArgs &a, int epi, int amode, hipStream_t stream);   // 304 x 128 panel tiling (gemm_panel_f32.hip)
+int launch_gemm_panel(const GemmArgs &a, int epi, int amode, hipStream_t stream, int height = 304);   // (32 T + 16) x 128 panels (gemm_panel_f32.hip)
 int launch_gemm_thin(const GemmArgs &a, int epi, hipStream_t stream);               // serving-size M (gemm_thin_f32.hip)
 bool gemm_thin_prefers(int M, int N);
 

@@ -101,7 +101,7 @@ def test_base_bs64_properties():
     # serving sizes run the 32x32 / 16x16x4 GEMM tiling (gemm_thin_f32.hip: all four GEMMs at one image, o_proj and fc2 up to
     # four) and the query-split attention launch (up to ten images): one image alone and five still reproduce their rows of
     # the 64-batch
-    for sel in ([11], [3, 60, 17, 41, 8]):
+    for sel in ([11], [3, 60, 17, 41, 8], list(range(20, 36))):       # 16 images: the 80-row panels on o_proj / fc2
         few = [h.cpu().numpy() for h in _run(m, x[sel]).hidden_states if h is not None]
         for a, b in zip(big, few):
             np.testing.assert_array_equal(a[sel], b)

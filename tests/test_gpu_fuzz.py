@@ -42,7 +42,7 @@ def _cleanup():
     os.environ.pop("LDIT_GEMM_FP8_TILE", None)
 
 
-@pytest.mark.parametrize("tile", ["auto", "0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("tile", ["auto", "0", "1", "2", "3", "4", "5", "6", "7"])
 def test_fuzz_linear_f32(tile):
     if tile != "auto":
         os.environ["LDIT_GEMM_TILE"] = tile

@@ -48,7 +48,7 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("tile", ["auto", "0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("tile", ["auto", "0", "1", "2", "3", "4", "5", "6", "7"])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_linear_bias(M, N, K, tile):
     if tile != "auto":
@@ -79,7 +79,7 @@ def test_linear_identity_asymmetric():
     np.testing.assert_array_equal(y, w.T)
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "3", "4", "5", "6", "7"])
 def test_linear_gelu_epilogue(tile):
     os.environ["LDIT_GEMM_TILE"] = tile
     M, N, K = 333, 320, 96
@@ -89,7 +89,7 @@ def test_linear_gelu_epilogue(tile):
     np.testing.assert_allclose(y, ref, rtol=1e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2", "3", "4"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "3", "4", "5", "6", "7"])
 def test_linear_scale_residual_inplace_and_tap(tile):
     """h <- h + lam * (x W^T + b), updated IN PLACE (R aliases Y) with a second copy to the tap buffer."""
     os.environ["LDIT_GEMM_TILE"] = tile
@@ -109,12 +109,13 @@ def test_linear_scale_residual_inplace_and_tap(tile):
 def test_thin_tiling_is_bit_identical_to_the_big_tilings(M, N, K):
     """The serving-size kernel (32x32 tiles of 16x16x4 MFMAs, LDIT_GEMM_TILE=4; the default while the 64x64 tiling
     would be at most 192 workgroups) keeps the k order
-    of the big tilings: every epilogue's output must be BIT-equal to the 64x64 tiling's (2) and to the panel tiling's (3),
-    which is what keeps a row's value independent of the batch it rides in."""
+    of the big tilings: every epilogue's output must be BIT-equal to the 64x64 tiling's (2) and to the panel tilings' (3: 304
+    rows; 5, 6, 7: the 144 / 80 / 48-row panels of the mid-size batches), which is what keeps a row's value independent of the
+    batch it rides in."""
     x, w, b = _rand(21, M, K), _rand(22, N, K, scale=0.05), _rand(23, N, scale=0.1)
     lam, r = np.abs(_rand(24, N)) * 0.3 + 0.05, _rand(25, M, N)
     outs = {}
-    for tile in ("4", "2", "3"):
+    for tile in ("4", "2", "3", "5", "6", "7"):
         os.environ["LDIT_GEMM_TILE"] = tile
         y0 = ops.linear(_dev(x), _dev(w), _dev(b))
         y1 = ops.linear(_dev(x), _dev(w), _dev(b), epilogue=_lib.EPI_BIAS_GELU)
@@ -122,7 +123,7 @@ def test_thin_tiling_is_bit_identical_to_the_big_tilings(M, N, K):
         ops.linear(_dev(x), _dev(w), _dev(b), epilogue=_lib.EPI_SCALE_RESID, lam=_dev(lam), residual=h, out=h)
         y3 = ops.linear(_dev(x), _dev(w))
         outs[tile] = [t.cpu().numpy() for t in (y0, y1, h, y3)]
-    for other in ("2", "3"):
+    for other in ("2", "3", "5", "6", "7"):
         for got, want in zip(outs["4"], outs[other]):
             np.testing.assert_array_equal(got, want)
     os.environ.pop("LDIT_GEMM_TILE")
