@@ -226,7 +226,8 @@ __global__ void __launch_bounds__(256) layernorm_bwd_rows(const float *__restric
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x + row * C);
         const f32x4 *d4 = reinterpret_cast<const f32x4 *>(dy + row * C);
-        f32x4 v[VPL], d[VPL];
+        f32x4 *h4 = reinterpret_cast<f32x4 *>(dh + row * C);
+        f32x4 v[VPL], d[VPL], acc[VPL];             // dh is fetched with x and dy: one memory round trip per row, not two
         float s = 0.0f;
 #pragma unroll
         for (int u = 0; u < VPL; ++u) {
@@ -234,10 +235,12 @@ __global__ void __launch_bounds__(256) layernorm_bwd_rows(const float *__restric
             if (idx < nvec) {
                 v[u] = x4[idx];
                 d[u] = d4[idx];
+                acc[u] = h4[idx];
                 s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
             } else {
                 v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
         const float mu = wave_sum(s) * inv_c;
@@ -268,12 +271,11 @@ __global__ void __launch_bounds__(256) layernorm_bwd_rows(const float *__restric
                 sb[u][e] += d[u][e];
             }
         const float m1 = wave_sum(s1) * inv_c, m2 = wave_sum(s2) * inv_c;
-        f32x4 *h4 = reinterpret_cast<f32x4 *>(dh + row * C);
 #pragma unroll
         for (int u = 0; u < VPL; ++u) {
             const int idx = lane + 64 * u;
             if (idx < nvec) {
-                f32x4 o = h4[idx];
+                f32x4 o = acc[u];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] += rstd * (d[u][e] * gg[u][e] - m1 - v[u][e] * m2);
                 h4[idx] = o;
@@ -531,7 +533,9 @@ int launch_rows_to_bf16(const float *src, void *dst, int M, int N, int skip_toke
     return LDIT_OK;
 }
 
-int layernorm_bwd_blocks(int64_t rows) { return (int)(rows < 4 * 512 ? (rows + 3) / 4 : 512); }
+// four workgroups of four waves per CU: a wave walks ~3 rows at bs=64, each one memory round trip - the latency is hidden by
+// the waves beside it, not inside it
+int layernorm_bwd_blocks(int64_t rows) { return (int)(rows < 4 * 1024 ? (rows + 3) / 4 : 1024); }
 
 int launch_layernorm_bwd(const float *dy, const float *x, const float *g, float *dh, int64_t rows, int C, float eps,
                          float *dg_part, float *db_part, hipStream_t stream)
@@ -542,6 +546,7 @@ int launch_layernorm_bwd(const float *dy, const float *x, const float *g, float 
     const int blocks = layernorm_bwd_blocks(rows);
     const size_t lds = (size_t)8 * C * sizeof(float);
     if (C <= 256) LAUNCH_CHECKED((layernorm_bwd_rows<1>), dim3(blocks), dim3(256), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
+    else if (C <= 768) LAUNCH_CHECKED((layernorm_bwd_rows<3>), dim3(blocks), dim3(256), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
     else if (C <= 1024) LAUNCH_CHECKED((layernorm_bwd_rows<4>), dim3(blocks), dim3(256), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
     else {
         static bool attr_set = false;
