@@ -204,14 +204,16 @@ __global__ void __launch_bounds__(256) resid_bwd_tile(const float *__restrict__ 
 // dh[row] += dx (the residual stream's gradient accumulates the branch's input gradient);  partial sums
 // dg_part[blk][c] = sum dy xhat,  db_part[blk][c] = sum dy.  One wave per row (row in registers, statistics recomputed
 // from the saved LN input exactly as the forward computes them), a workgroup of 4 waves walks rows blk*4+w, +4*grid, ...
-template <int VPL>
-__global__ void __launch_bounds__(256) layernorm_bwd_rows(const float *__restrict__ dy, const float *__restrict__ x,
+// NWV waves per workgroup: 512 workgroups x 8 waves fill the chip at four waves per SIMD (C <= 1024); rows of up to 4096
+// floats keep 4 waves (498 registers, 128 KB of reduction buffer)
+template <int VPL, int NWV>
+__global__ void __launch_bounds__(64 * NWV) layernorm_bwd_rows(const float *__restrict__ dy, const float *__restrict__ x,
                                                           const float *__restrict__ g, float *__restrict__ dh, int64_t rows,
                                                           int C, float eps, float *__restrict__ dg_part,
                                                           float *__restrict__ db_part)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_ln[];
-    float *red = reinterpret_cast<float *>(smem_ln);          // [2][4][C]
+    float *red = reinterpret_cast<float *>(smem_ln);          // [2][NWV][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = C >> 2;
     const float inv_c = 1.0f / (float)C;
@@ -223,7 +225,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_rows(const float *__restric
         sg[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         sb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    for (int64_t row = (int64_t)blockIdx.x * NWV + wave; row < rows; row += (int64_t)gridDim.x * NWV) {
         const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x + row * C);
         const f32x4 *d4 = reinterpret_cast<const f32x4 *>(dy + row * C);
         f32x4 *h4 = reinterpret_cast<f32x4 *>(dh + row * C);
@@ -282,19 +284,25 @@ __global__ void __launch_bounds__(256) layernorm_bwd_rows(const float *__restric
             }
         }
     }
-    // the four waves' column sums -> one partial row per workgroup
+    // the waves' column sums -> one partial row per workgroup (fixed order)
 #pragma unroll
     for (int u = 0; u < VPL; ++u) {
         const int idx = lane + 64 * u;
         if (idx < nvec) {
-            reinterpret_cast<f32x4 *>(red + (0 * 4 + wave) * C)[idx] = sg[u];
-            reinterpret_cast<f32x4 *>(red + (1 * 4 + wave) * C)[idx] = sb[u];
+            reinterpret_cast<f32x4 *>(red + (0 * NWV + wave) * C)[idx] = sg[u];
+            reinterpret_cast<f32x4 *>(red + (1 * NWV + wave) * C)[idx] = sb[u];
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        dg_part[(size_t)blockIdx.x * C + c] = (red[(0 * 4 + 0) * C + c] + red[(0 * 4 + 1) * C + c]) + (red[(0 * 4 + 2) * C + c] + red[(0 * 4 + 3) * C + c]);
-        db_part[(size_t)blockIdx.x * C + c] = (red[(1 * 4 + 0) * C + c] + red[(1 * 4 + 1) * C + c]) + (red[(1 * 4 + 2) * C + c] + red[(1 * 4 + 3) * C + c]);
+    for (int c = threadIdx.x; c < C; c += 64 * NWV) {
+        float a = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) {
+            a += red[(0 * NWV + w) * C + c];
+            b += red[(1 * NWV + w) * C + c];
+        }
+        dg_part[(size_t)blockIdx.x * C + c] = a;
+        db_part[(size_t)blockIdx.x * C + c] = b;
     }
 }
 
@@ -533,9 +541,10 @@ int launch_rows_to_bf16(const float *src, void *dst, int M, int N, int skip_toke
     return LDIT_OK;
 }
 
-// four workgroups of four waves per CU: a wave walks ~3 rows at bs=64, each one memory round trip - the latency is hidden by
-// the waves beside it, not inside it
-int layernorm_bwd_blocks(int64_t rows) { return (int)(rows < 4 * 1024 ? (rows + 3) / 4 : 1024); }
+// two workgroups of eight waves per CU: a wave walks ~3 rows at bs=64, each one memory round trip - the latency is hidden by
+// the waves beside it, not inside it - and 512 partial rows per gradient vector (1024 four-wave workgroups hid it as well but
+// doubled the second-stage reduction)
+int layernorm_bwd_blocks(int64_t rows) { return (int)(rows < 8 * 512 ? (rows + 7) / 8 : 512); }
 
 int launch_layernorm_bwd(const float *dy, const float *x, const float *g, float *dh, int64_t rows, int C, float eps,
                          float *dg_part, float *db_part, hipStream_t stream)
@@ -544,18 +553,18 @@ int launch_layernorm_bwd(const float *dy, const float *x, const float *g, float 
     if ((C & 3) || C > 4096) return fail(LDIT_EUNSUPPORTED, "layernorm_bwd: C=%d must be a multiple of 4, at most 4096", C);
     if (!dy || !x || !g || !dh || !dg_part || !db_part) return fail(LDIT_EINVAL, "layernorm_bwd: null operand");
     const int blocks = layernorm_bwd_blocks(rows);
-    const size_t lds = (size_t)8 * C * sizeof(float);
-    if (C <= 256) LAUNCH_CHECKED((layernorm_bwd_rows<1>), dim3(blocks), dim3(256), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
-    else if (C <= 768) LAUNCH_CHECKED((layernorm_bwd_rows<3>), dim3(blocks), dim3(256), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
-    else if (C <= 1024) LAUNCH_CHECKED((layernorm_bwd_rows<4>), dim3(blocks), dim3(256), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
+    const size_t lds = (size_t)2 * (C <= 1024 ? 8 : 4) * C * sizeof(float);
+    if (C <= 256) LAUNCH_CHECKED((layernorm_bwd_rows<1, 8>), dim3(blocks), dim3(512), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
+    else if (C <= 768) LAUNCH_CHECKED((layernorm_bwd_rows<3, 8>), dim3(blocks), dim3(512), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
+    else if (C <= 1024) LAUNCH_CHECKED((layernorm_bwd_rows<4, 8>), dim3(blocks), dim3(512), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
     else {
         static bool attr_set = false;
         if (!attr_set) {
-            LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(layernorm_bwd_rows<16>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4096 * 4));
+            LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(layernorm_bwd_rows<16, 4>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 4096 * 4));
             attr_set = true;
         }
-        LAUNCH_CHECKED((layernorm_bwd_rows<16>), dim3(blocks), dim3(256), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
+        LAUNCH_CHECKED((layernorm_bwd_rows<16, 4>), dim3(blocks), dim3(256), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
     }
     return LDIT_OK;
 }
