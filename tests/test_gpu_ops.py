@@ -131,6 +131,36 @@ def test_thin_tiling_is_bit_identical_to_the_big_tilings(M, N, K):
     np.testing.assert_array_equal(auto, outs["4"][0])
 
 
+@pytest.mark.parametrize("tile", ["auto", "0", "1", "2", "3", "4", "6"])
+def test_linear_row_strides_through_the_c_abi(tile):
+    """lda > K and ldy > N (operands that are column slices of wider buffers: the fused q|k|v tensor, an output written into
+    a slice of a concatenated map) on every fp32 tiling; the columns outside the slice must stay untouched."""
+    if tile != "auto":
+        os.environ["LDIT_GEMM_TILE"] = tile
+    lib = _lib.load()
+    M, N, K, lda, ldy = 211, 96, 64, 160, 224
+    xw = _rand(31, M, lda)
+    w, b = _rand(32, N, K, scale=0.1), _rand(33, N, scale=0.2)
+    lam, r = np.abs(_rand(34, N)) + 0.05, _rand(35, M, ldy)
+    x_t, w_t, b_t, lam_t = _dev(xw), _dev(w), _dev(b), _dev(lam)
+    for epi in (_lib.EPI_BIAS, _lib.EPI_BIAS_GELU, _lib.EPI_SCALE_RESID):
+        y_t = _dev(r)                                    # doubles as the residual (in place) for EPI_SCALE_RESID
+        xs, ys = x_t[:, 32:32 + K], y_t[:, 64:64 + N]     # 16-byte aligned column slices
+        rc = lib.ldit_linear_f32(xs.data_ptr(), lda, w_t.data_ptr(), b_t.data_ptr(), ys.data_ptr(), ldy, M, N, K, epi,
+                                 lam_t.data_ptr() if epi == _lib.EPI_SCALE_RESID else None,
+                                 ys.data_ptr() if epi == _lib.EPI_SCALE_RESID else None, None, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.ldit_last_error().decode()
+        got = y_t.cpu().numpy()
+        ref = oracle.linear(xw[:, 32:32 + K], w, b)
+        if epi == _lib.EPI_BIAS_GELU:
+            ref = oracle.gelu(ref)
+        if epi == _lib.EPI_SCALE_RESID:
+            ref = (r[:, 64:64 + N].astype(np.float64) + lam.astype(np.float64) * ref.astype(np.float64)).astype(np.float32)
+        assert rel_l2(got[:, 64:64 + N], ref) < 1e-5, (tile, epi)
+        np.testing.assert_array_equal(got[:, :64], r[:, :64])
+        np.testing.assert_array_equal(got[:, 64 + N:], r[:, 64 + N:])
+
+
 def test_linear_rejects_bad_arguments():
     x, w = _dev(_rand(1, 8, 40)), _dev(_rand(2, 8, 40))
     with pytest.raises(_lib.LditError) as e:        # K not a multiple of 32
