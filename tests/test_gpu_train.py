@@ -92,7 +92,7 @@ def test_attention_backward_rejects_long_sequences():
 
 
 # ---- LayerNorm backward -----------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("rows,Cc", [(394, 768), (5, 192), (3000, 1024), (68, 128)])
+@pytest.mark.parametrize("rows,Cc", [(394, 768), (5, 192), (3000, 1024), (68, 128), (9000, 768), (40, 2048)])
 def test_layernorm_backward(rows, Cc):
     lib = _lib.load()
     x = _rand(11, rows, Cc) * 2.0 + 0.5
