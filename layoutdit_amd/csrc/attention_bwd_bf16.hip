@@ -85,33 +85,44 @@ __global__ void __launch_bounds__(512, 2) attention_bwd_bf16(const bf16_t *__res
     const int head = blockIdx.x % H, b = blockIdx.x / H;
     const size_t tok0 = (size_t)b * N;
 
-    // ---- stage the head: 16-B chunk (row, ch) per thread and pass; delta = rowsum(dO . O) on the way ---------------
-    for (int r0 = 0; r0 < NP; r0 += 64) {
-        const int row = r0 + (tid >> 3), ch = tid & 7;
-        bf16x8 q = {}, k = {}, v = {}, g = {}, o = {};
-        if (row < N) {
-            const size_t t = tok0 + row;
-            q = *reinterpret_cast<const bf16x8 *>(Q + t * ldqkv + head * 64 + 8 * ch);
-            k = *reinterpret_cast<const bf16x8 *>(K + t * ldqkv + head * 64 + 8 * ch);
-            v = *reinterpret_cast<const bf16x8 *>(V + t * ldqkv + head * 64 + 8 * ch);
-            g = *reinterpret_cast<const bf16x8 *>(dO + t * lddo + head * 64 + 8 * ch);
-            o = *reinterpret_cast<const bf16x8 *>(O + t * ldo + head * 64 + 8 * ch);
-        }
-        float d = 0.0f;
+    // ---- stage the head: 16-B chunk (row, ch) per thread and pass; delta = rowsum(dO . O) on the way.  All passes' loads
+    //      (up to 4 x 5 chunks) are issued before the first LDS store: one memory round trip for the head, not one per pass.
+    {
+        constexpr int PASSES = 4;                       // N <= 256 rows, 64 rows per pass
+        bf16x8 q[PASSES], k[PASSES], v[PASSES], g[PASSES], o[PASSES];
+        const int ch = tid & 7;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d = __builtin_fmaf((float)g[e], (float)o[e], d);
-        d += __shfl_xor(d, 1, 64);
-        d += __shfl_xor(d, 2, 64);
-        d += __shfl_xor(d, 4, 64);
-        if (row < NP) {
-            const int off = img_off(row, ch);
-            *reinterpret_cast<bf16x8 *>(Qs + off) = q;
-            *reinterpret_cast<bf16x8 *>(Ks + off) = k;
-            *reinterpret_cast<bf16x8 *>(Vs + off) = v;
-            *reinterpret_cast<bf16x8 *>(Gs + off) = g;
-            if (ch == 0) {
-                dlt[row] = d;
-                L2s[row] = row < N ? lse[((size_t)b * H + head) * N + row] : 0.0f;
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int row = 64 * ps + (tid >> 3);
+            q[ps] = bf16x8{}; k[ps] = bf16x8{}; v[ps] = bf16x8{}; g[ps] = bf16x8{}; o[ps] = bf16x8{};
+            if (row < N) {
+                const size_t t = tok0 + row;
+                q[ps] = *reinterpret_cast<const bf16x8 *>(Q + t * ldqkv + head * 64 + 8 * ch);
+                k[ps] = *reinterpret_cast<const bf16x8 *>(K + t * ldqkv + head * 64 + 8 * ch);
+                v[ps] = *reinterpret_cast<const bf16x8 *>(V + t * ldqkv + head * 64 + 8 * ch);
+                g[ps] = *reinterpret_cast<const bf16x8 *>(dO + t * lddo + head * 64 + 8 * ch);
+                o[ps] = *reinterpret_cast<const bf16x8 *>(O + t * ldo + head * 64 + 8 * ch);
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int row = 64 * ps + (tid >> 3);
+            float d = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d = __builtin_fmaf((float)g[ps][e], (float)o[ps][e], d);
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            if (row < NP) {
+                const int off = img_off(row, ch);
+                *reinterpret_cast<bf16x8 *>(Qs + off) = q[ps];
+                *reinterpret_cast<bf16x8 *>(Ks + off) = k[ps];
+                *reinterpret_cast<bf16x8 *>(Vs + off) = v[ps];
+                *reinterpret_cast<bf16x8 *>(Gs + off) = g[ps];
+                if (ch == 0) {
+                    dlt[row] = d;
+                    L2s[row] = row < N ? lse[((size_t)b * H + head) * N + row] : 0.0f;
+                }
             }
         }
     }
