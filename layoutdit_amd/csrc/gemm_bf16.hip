@@ -13,6 +13,7 @@
 // Epilogues: bias -> bf16 ; bias + erf-GELU -> bf16 ; R + lam (.) (acc + bias) -> fp32 (in place on the fp32 residual
 // stream, optional fp32 tap copy).
 #include <cstdlib>
+#include <type_traits>
 
 #include "gemm_bf16_common.h"
 
@@ -34,8 +35,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
 {
     GemmArgsH p = p0;
     constexpr int NWAVES = WM * WN;
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, ROWS = BM + BN, NLD = ROWS / (8 * NWAVES);
-    static_assert(ROWS % (8 * NWAVES) == 0 && BM % 8 == 0, "DMA pieces must split evenly over the waves");
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, ROWS = BM + BN;
+    static_assert(BM % 8 == 0, "a DMA piece is eight rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -63,12 +64,25 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     }
     const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
 
-    unsigned src[NLD];   // element (bf16) offsets
+    // LDS-DMA roles.  With two waves per SIMD (the 8-wave tiles) only waves 0..3 - one per SIMD - issue DMA pieces, twice as
+    // many each; waves 4..7 issue none.  A piece blocks the issuing wave's instruction stream for tens of cycles; with both
+    // waves of a SIMD issuing at the 256 x 256 tile's density (4 pieces per 16 MFMAs and wave) the matrix pipe idles 46 % of
+    // the time, with one loader per SIMD the partner's MFMAs cover the stall: 123 -> 70 cycles per MFMA against 64 without
+    // any DMA (scripts/ubench/dma_issue.hip, profiles/r02_dma_issue.txt).  In the kernel the gain is smaller - the loader must
+    // still reach every hand-over barrier: ViT-L/16 512x512 bs=16 forward 15.75 -> 15.40 ms (raising the loaders' priority
+    // with s_setprio changes nothing).  The 4-wave tiles stay symmetric.
+    // (the 320-row tile with the residual / fp32 epilogues has no registers left for the loaders' 18 source offsets: symmetric)
+    constexpr bool SPLIT = NWAVES == 8 && !(TM == 5 && (EPI == EPI_SCALE_RESID || EPI == EPI_F32));
+    constexpr int LW = SPLIT ? NWAVES / 2 : NWAVES;      // waves that issue
+    constexpr int NLW = ROWS / (8 * LW);                 // pieces per issuing wave and k-tile
+    static_assert(ROWS % (8 * LW) == 0, "DMA pieces must split evenly over the issuing waves");
+    const bool loader = !SPLIT || wave < LW;             // wave-uniform
+    unsigned src[NLW];   // element (bf16) offsets
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-        const int row = 8 * (wave + NWAVES * u) + (lane >> 3);
+    for (int u = 0; u < NLW; ++u) {
+        const int row = 8 * ((wave % LW) + LW * u) + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        if (8 * (wave + NWAVES * u) < BM) {
+        if (8 * ((wave % LW) + LW * u) < BM) {
             int gm = m0 + row;
             gm = gm < p.M ? gm : p.M - 1;
             src[u] = (unsigned)gm * (unsigned)p.lda + c * 8;
@@ -78,11 +92,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
             src[u] = (unsigned)gn * (unsigned)p.K + c * 8;
         }
     }
-    auto issue = [&](int stage, int k0) {
+    auto issue_range = [&](int stage, int k0, int lo, int hi) {
         char *base = smem + stage * (ROWS * ROWB);
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int piece = wave + NWAVES * u;
+        for (int u = 0; u < NLW; ++u) {
+            if (u < lo || u >= hi) continue;
+            const int piece = (wave % LW) + LW * u;
             const bf16_t *opnd = 8 * piece < BM ? p.A : p.W;
             glds16h(opnd + (src[u] + (unsigned)k0), base + piece * 1024);
         }
@@ -120,25 +135,22 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     //   freed their stage) and steps 0 and 1, so the last of them still has ~2 steps of MFMA time to land.
     constexpr int SG_MFMA = 0x8, SG_VMEM = 0x20, SG_DSR = 0x100;
     constexpr int NM = TM * TN, NF = TM + TN;
-    constexpr int D3 = (NLD + 2) / 3, D0 = (NLD - D3 + 1) / 2, D1 = NLD - D3 - D0;      // pieces issued in steps 3 / 0 / 1
     static_assert(NF <= NM, "fewer MFMAs than fragment reads per step");
-    auto issue_range = [&](int stage, int k0, int lo, int hi) {
-        char *base = smem + stage * (ROWS * ROWB);
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            if (u < lo || u >= hi) continue;
-            const int piece = wave + NWAVES * u;
-            const bf16_t *opnd = 8 * piece < BM ? p.A : p.W;
-            glds16h(opnd + (src[u] + (unsigned)k0), base + piece * 1024);
-        }
-    };
     bf16x8 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
-    issue(0, 0);
+#ifdef LDIT_GEMM_STAMPS
+    unsigned long long st_vm = 0, st_bar = 0, st_loop0 = 0;
+#endif
+    // the k-loop, instantiated per role: NP = DMA pieces this wave issues per k-tile (0 for the non-loaders of a SPLIT tile)
+    auto kloop = [&](auto np_c) {
+    constexpr int NP = decltype(np_c)::value;
+    // pieces issued in steps 3 / 0 / 1; a SPLIT loader issues all of them right behind the hand-over (twice the pieces: the last
+    // ones need the whole k-tile to land)
+    constexpr int D3 = SPLIT ? NP : (NP + 2) / 3, D0 = SPLIT ? 0 : (NP - D3 + 1) / 2, D1 = NP - D3 - D0;
+    issue_range(0, 0, 0, NP);
     issue_range(1, (nk > 1 ? 1 : 0) * BKB, 0, D3);
     __syncthreads();
 #ifdef LDIT_GEMM_STAMPS
-    unsigned long long st_vm = 0, st_bar = 0;
-    const unsigned long long st_loop0 = __builtin_amdgcn_s_memtime();
+    st_loop0 = __builtin_amdgcn_s_memtime();
 #endif
     load_frags(0, 0, xa0, wb0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -163,7 +175,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
         __builtin_amdgcn_sched_barrier(0);
         // ---- step 1
         load_frags(cur, 2, xa0, wb0);
-        issue_range(cur ^ 1, k1, D3 + D0, NLD);
+        issue_range(cur ^ 1, k1, D3 + D0, NP);
         mfma_step(xa1, wb1);
 #pragma unroll
         for (int g = 0; g < NF; ++g) {
@@ -199,6 +211,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
             st_vm += h1 - h0; st_bar += h2 - h1;
         }
 #else
+        // explicit: hipcc does NOT put a vmcnt wait in front of this barrier for LDS-DMA pieces issued behind the PREVIOUS
+        // hand-over (a loader's pieces all are) - other waves would read a stage that has not landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #endif
         // ---- step 3: MFMAs of the last fragments | first fragments of tile kt+1 | first DMA pieces of tile kt+2 -> stage cur
@@ -217,6 +232,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
         }
         if (NM - NF - D3 > 0) __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF - D3, 3);
     }
+    };
+    if (loader) kloop(std::integral_constant<int, NLW>{});
+    else kloop(std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches of the tail must not outlive the LDS allocation
 #ifdef LDIT_GEMM_STAMPS
     asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][15]));

@@ -183,6 +183,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         mfma_step(xa1, wb1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: do not rely on hipcc to drain the LDS-DMA in front of the barrier
         __syncthreads();            // own DMA of tile kt+1 landed (vmcnt 0), every wave done reading stage cur
     }
 

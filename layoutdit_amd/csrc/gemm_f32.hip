@@ -271,6 +271,7 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(const GemmArgs p)
         __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF, 2);
         __builtin_amdgcn_sched_barrier(0);
         // ---- hand-over: own DMA landed (vmcnt 0), own reads of stage cur done (lgkmcnt 0), then all waves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: do not rely on hipcc to drain the LDS-DMA in front of the barrier
         __syncthreads();
         // ---- chunk 3: MFMAs of f1 | read chunk 0 of the next stage -> f0
         load_frags(cur ^ 1, 0, fa0, fb0);

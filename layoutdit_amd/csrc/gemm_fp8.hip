@@ -221,6 +221,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_fp8_mfma(con
             load_frags(cur, 3, xa1, wb1);
             __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(xa0, wb0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: do not rely on hipcc to drain the LDS-DMA in front of the barrier
             __syncthreads();   // hand-over: tile kt+1 landed in every wave, stage cur released
             load_frags(cur ^ 1, 0, xa0, wb0);
             mfma_chunk(xa1, wb1);
@@ -259,6 +260,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_fp8_mfma(con
             load_frags(cur, 1, xa1, wb1);
             issue(cur ^ 1, knext);
             mfma_chunk(xa0, wb0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: do not rely on hipcc to drain the LDS-DMA in front of the barrier
             __syncthreads();   // hand-over: tile kt+1 landed in every wave, stage cur released (its last reads are in xa1/wb1)
             load_frags(cur ^ 1, 0, xa0, wb0);
             mfma_chunk(xa1, wb1);

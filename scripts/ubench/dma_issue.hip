@@ -7,7 +7,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int D, int NW, int WAITEVERY = 4>
+template <int D, int NW, int WAITEVERY = 4, bool ASYM = false>
 __global__ void __launch_bounds__(64 * NW) k(const float *src, unsigned long long *out, float *sink, int iters)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(64 * NW) k(const float *src, unsigned long lon
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m & 3], 0, 0, 0);
-            if (D > 0 && (m % (16 / (D > 16 ? 16 : D))) == 0) {
+            if (D > 0 && (m % (16 / (D > 16 ? 16 : D))) == 0 && (!ASYM || wave < NW / 2)) {
 #pragma unroll
                 for (int r = 0; r < (D > 16 ? D / 16 : 1); ++r)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + ((it * 16 + m) & 63) * 256),
@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(64 * NW) k(const float *src, unsigned long lon
         if (D > 0 && (it % WAITEVERY) == WAITEVERY - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // wave 0 times the whole workgroup
     float s = 0;
     for (int c = 0; c < 4; ++c) s += acc[c][0] + acc[c][15];
     asm volatile("s_nop 0" ::"v"(s));
@@ -43,16 +44,16 @@ __global__ void __launch_bounds__(64 * NW) k(const float *src, unsigned long lon
     sink[blockIdx.x * 64 * NW + threadIdx.x] = s + smem[threadIdx.x];
 }
 
-template <int D, int NW, int WAITEVERY = 4>
+template <int D, int NW, int WAITEVERY = 4, bool ASYM = false>
 void run(const float *src, unsigned long long *out, float *sink, const char *what)
 {
     const int iters = 256;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(k<D, NW, WAITEVERY>), hipFuncAttributeMaxDynamicSharedMemorySize, NW * 16384);
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<D, NW, WAITEVERY>), dim3(256), dim3(64 * NW), NW * 16384, 0, src, out, sink, iters);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k<D, NW, WAITEVERY, ASYM>), hipFuncAttributeMaxDynamicSharedMemorySize, NW * 16384);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<D, NW, WAITEVERY, ASYM>), dim3(256), dim3(64 * NW), NW * 16384, 0, src, out, sink, iters);
     hipDeviceSynchronize();
     unsigned long long h;
     hipMemcpy(&h, out, 8, hipMemcpyDeviceToHost);
-    printf("%-28s D = %2d pieces per 16 MFMAs, vmcnt(0) every %2d blocks: %6.1f cycles per MFMA\n", what, D, WAITEVERY, (double)h / (iters * 16));
+    printf("%-28s D = %2d pieces per 16 MFMAs%s, vmcnt(0) every %2d blocks: %6.1f cycles per MFMA\n", what, D, ASYM ? " on waves 0..NW/2-1 only" : "", WAITEVERY, (double)h / (iters * 16));
 }
 
 int main()
@@ -70,5 +71,6 @@ int main()
     run<3, 8>(src, out, sink, "8 waves (2 per SIMD)");
     run<4, 8, 1>(src, out, sink, "8 waves (2 per SIMD)"); run<4, 8, 2>(src, out, sink, "8 waves (2 per SIMD)"); run<4, 8, 16>(src, out, sink, "8 waves (2 per SIMD)");
     run<2, 8, 1>(src, out, sink, "8 waves (2 per SIMD)"); run<8, 4, 1>(src, out, sink, "4 waves (1 per SIMD)"); run<8, 4, 16>(src, out, sink, "4 waves (1 per SIMD)");
+    run<8, 8, 4, true>(src, out, sink, "8 waves (2 per SIMD)"); run<16, 8, 4, true>(src, out, sink, "8 waves (2 per SIMD)"); run<4, 8, 4, true>(src, out, sink, "8 waves (2 per SIMD)");
     return 0;
 }
