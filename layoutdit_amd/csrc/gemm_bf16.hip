@@ -72,7 +72,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     // still reach every hand-over barrier: ViT-L/16 512x512 bs=16 forward 15.75 -> 15.40 ms (raising the loaders' priority
     // with s_setprio changes nothing).  The 4-wave tiles stay symmetric.
     // (the 320-row tile with the residual / fp32 epilogues has no registers left for the loaders' 18 source offsets: symmetric)
+#ifdef LDIT_BF16_NO_SPLIT            // A/B build only (scripts/ab_bf16_split.sh): every wave issues its own pieces, as in round 1
+    constexpr bool SPLIT = false;
+#else
     constexpr bool SPLIT = NWAVES == 8 && !(TM == 5 && (EPI == EPI_SCALE_RESID || EPI == EPI_F32));
+#endif
     constexpr int LW = SPLIT ? NWAVES / 2 : NWAVES;      // waves that issue
     constexpr int NLW = ROWS / (8 * LW);                 // pieces per issuing wave and k-tile
     static_assert(ROWS % (8 * LW) == 0, "DMA pieces must split evenly over the issuing waves");
