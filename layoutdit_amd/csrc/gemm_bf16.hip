@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     constexpr int D3 = SPLIT ? NP : (NP + 2) / 3, D0 = SPLIT ? 0 : (NP - D3 + 1) / 2, D1 = NP - D3 - D0;
     issue_range(0, 0, 0, NP);
     issue_range(1, (nk > 1 ? 1 : 0) * BKB, 0, D3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tile has landed before anybody reads it
     __syncthreads();
 #ifdef LDIT_GEMM_STAMPS
     st_loop0 = __builtin_amdgcn_s_memtime();

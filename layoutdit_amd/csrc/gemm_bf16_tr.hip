@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
 
     bf16x8 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
     issue(0, kbeg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tile has landed before anybody reads it
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;

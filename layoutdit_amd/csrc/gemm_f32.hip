@@ -220,6 +220,7 @@ __global__ void __launch_bounds__(256) gemm_f32_mfma(const GemmArgs p)
     static_assert(NF <= NM, "fewer MFMAs than fragment reads in a chunk");
     f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
     issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tile has landed before anybody reads it
     __syncthreads();
 #ifdef LDIT_GEMM_STAMPS
     st_clk1 = __builtin_amdgcn_s_memtime();

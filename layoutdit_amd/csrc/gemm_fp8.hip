@@ -208,6 +208,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_fp8_mfma(con
         };
         i64x2 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
         issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tile has landed before anybody reads it
         __syncthreads();
         load_frags(0, 0, xa0, wb0);
         for (int kt = 0; kt < nk; ++kt) {
@@ -252,6 +253,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_fp8_mfma(con
         };
         i32x8 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
         issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tile has landed before anybody reads it
         __syncthreads();
         load_frags(0, 0, xa0, wb0);
         for (int kt = 0; kt < nk; ++kt) {

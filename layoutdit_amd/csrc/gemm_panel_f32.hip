@@ -315,6 +315,7 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
 
     Frags f0, f1;
     issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tile has landed before anybody reads it
     __syncthreads();
 #ifdef LDIT_GEMM_STAMPS
     st_clk1 = __builtin_amdgcn_s_memtime();
