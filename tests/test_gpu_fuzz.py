@@ -64,7 +64,7 @@ def test_fuzz_linear_f32(tile):
         assert np.isfinite(y).all()
 
 
-@pytest.mark.parametrize("tile", ["auto", "1", "2", "3"])
+@pytest.mark.parametrize("tile", ["auto", "1", "2", "3", "4", "5"])
 def test_fuzz_linear_bf16(tile):
     if tile != "auto":
         os.environ["LDIT_GEMM_BF16_TILE"] = tile
@@ -86,7 +86,7 @@ def test_fuzz_linear_bf16(tile):
         assert rel_l2(y, ref) < (1e-5 if epi == _lib.EPI_SCALE_RESID else 4e-3), (tile, M, N, K, epi)
 
 
-@pytest.mark.parametrize("tile", ["auto", "0", "1", "2"])
+@pytest.mark.parametrize("tile", ["auto", "0", "1", "2", "3", "4"])
 def test_fuzz_linear_fp8(tile):
     """fp8 GEMM on the same ragged shapes; reference = oracle on the dequantised codes (gates: tests/test_gpu_fp8.py)."""
     if tile != "auto":
