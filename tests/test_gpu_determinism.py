@@ -41,7 +41,8 @@ def test_attention_f32_repeats_bit_exactly(B, N, H):
     _same(lambda: ops.attention(qkv[..., :C_], qkv[..., C_:2 * C_], qkv[..., 2 * C_:], H))
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(12608, 2304, 768, 0), (12608, 768, 3072, 2), (16400, 4096, 1024, 1), (6304, 768, 768, 2)])
+@pytest.mark.parametrize("M,N,K,epi", [(12608, 2304, 768, 0), (12608, 768, 3072, 2), (16400, 4096, 1024, 1), (6304, 768, 768, 2),
+                                       (197, 768, 3072, 2), (394, 2304, 768, 0), (3152, 768, 768, 2), (1576, 768, 3072, 2)])
 def test_gemms_repeat_bit_exactly(M, N, K, epi):
     x, w = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV) * 0.05
     b, lam, r = torch.randn(N, device=DEV), torch.rand(N, device=DEV), torch.randn(M, N, device=DEV)
