@@ -11,8 +11,10 @@
  * Conventions
  *   - plain C, no torch / HIP types in signatures; `ldit_stream` is a hipStream_t passed as void* (NULL = default stream)
  *   - every pointer is a DEVICE pointer owned by the caller, 16-byte aligned, fp32 unless stated
- *   - the library allocates nothing, keeps no mutable global state, and only ENQUEUES work on `stream`
- *     (asynchronous to the host; the caller synchronises) - safe to capture in a hipGraph
+ *   - the library allocates nothing and only ENQUEUES work on `stream` (asynchronous to the host; the caller synchronises)
+ *     - safe to capture in a hipGraph.  Its only mutable process state: one bit per (kernel, device ordinal) recording that
+ *     the kernel's dynamic-LDS limit was raised on that device (set lazily on the CURRENT device of the calling thread, which
+ *     must be the device `stream` belongs to), and the diagnostic switches below (read from the environment once)
  *   - returns LDIT_OK (0) or a negative LDIT_E* code; ldit_last_error() returns a thread-local message
  *   - there is NO CPU fallback in this library: without a HIP device every compute entry point fails with LDIT_EHIP
  */
@@ -113,6 +115,10 @@ typedef struct ldit_weights {
 /* ---- library ------------------------------------------------------------------------------------------------ */
 int ldit_abi_version(void);
 const char *ldit_last_error(void);
+/* Diagnostic: the LDIT_* environment switches that force a tiling (tests reach every kernel instantiation through them; see
+ * layoutdit_amd/csrc/ldit_common.h: DiagSwitches) are read ONCE, at first use; this re-reads them after the caller changed
+ * one.  Not thread-safe against concurrent launches. */
+int ldit_debug_reload_env(void);
 
 /* ---- whole path: replaces `self.dit(x).hidden_states` (ref dit_backbone.py:47 ; TF:515-560) ------------------- */
 

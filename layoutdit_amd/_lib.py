@@ -46,6 +46,7 @@ _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_si
 SIGNATURES = {
     "ldit_abi_version": (C.c_int, []),
     "ldit_last_error": (C.c_char_p, []),
+    "ldit_debug_reload_env": (C.c_int, []),
     "ldit_packed_bytes": (_sz, [C.POINTER(LditCfg)]),
     "ldit_pack_weights": (C.c_int, [C.POINTER(LditCfg), C.POINTER(LditWeights), _vp, _sz, _vp]),
     "ldit_workspace_bytes": (_sz, [C.POINTER(LditCfg), _i32]),
@@ -122,6 +123,16 @@ def load() -> C.CDLL:
             raise ImportError(f"libldit_hip ABI {got} != expected {LDIT_ABI_VERSION}")
         _lib = lib
     return _lib
+
+
+def set_switch(name: str, value) -> None:
+    """Set (``value`` a string) or remove (``None``) one of the library's diagnostic ``LDIT_*`` environment switches and make
+    the library re-read them: it reads its switches once, not per launch (``ldit_debug_reload_env``, include/ldit.h)."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    load().ldit_debug_reload_env()
 
 
 def check(rc: int) -> None:

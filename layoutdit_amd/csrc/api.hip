@@ -19,6 +19,49 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+int ensure_dynamic_lds(const void *kern, int bytes, std::atomic<unsigned long long> &done)
+{
+    int dev = 0;
+    LDIT_HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+    if (bit && (done.load(std::memory_order_relaxed) & bit)) return LDIT_OK;
+    LDIT_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (bit) done.fetch_or(bit, std::memory_order_relaxed);
+    return LDIT_OK;
+}
+
+namespace {
+DiagSwitches read_switches()
+{
+    DiagSwitches d;
+    auto digit = [](const char *name, int lo, int hi) {
+        const char *e = getenv(name);
+        return (e && e[0] >= '0' + lo && e[0] <= '0' + hi && e[1] == 0) ? e[0] - '0' : -1;
+    };
+    auto is = [](const char *name, char c) { const char *e = getenv(name); return e && e[0] == c; };
+    d.gemm_tile = digit("LDIT_GEMM_TILE", 0, 7);
+    if (const char *e = getenv("LDIT_GEMM_THIN_TILES")) d.thin_tiles = atol(e);
+    d.panel_r16_vec = is("LDIT_PANEL_R16", 'v');
+    d.bf16_tile = digit("LDIT_GEMM_BF16_TILE", 2, 7);
+    d.bf16_tile_env = getenv("LDIT_GEMM_BF16_TILE") != nullptr;
+    d.bf16_tr_tile = digit("LDIT_GEMM_BF16_TR_TILE", 0, 9);
+    d.fp8_tile = digit("LDIT_GEMM_FP8_TILE", 0, 6);
+    d.fp8_k16 = is("LDIT_GEMM_FP8_K16", '1');
+    d.fp8_noskinny = is("LDIT_GEMM_FP8_NOSKINNY", '1');
+    d.direct_epi = is("LDIT_GEMM_DIRECT_EPILOGUE", '1');
+    d.attn_bf16_kt4 = is("LDIT_ATTN_BF16_KT", '4');
+    return d;
+}
+DiagSwitches &switches()
+{
+    static DiagSwitches d = read_switches();
+    return d;
+}
+}  // namespace
+
+const DiagSwitches &diag() { return switches(); }
+void reload_diag() { switches() = read_switches(); }
+
 namespace {
 
 int embed(const Geo &g, const float *x, const float *pw, const float *pb, const float *cls, const float *pos, float *out,
@@ -161,6 +204,13 @@ using namespace ldit;
 extern "C" {
 
 int ldit_abi_version(void) { return LDIT_ABI_VERSION; }
+
+/* diagnostic: re-read the LDIT_* switches of ldit_common.h from the environment (they are otherwise read once) */
+int ldit_debug_reload_env(void)
+{
+    reload_diag();
+    return LDIT_OK;
+}
 
 const char *ldit_last_error(void) { return err_buf(); }
 

@@ -299,14 +299,11 @@ static int launch_attn(const void *Q, const void *K, const void *V, void *O, int
     if ((ldq | ldk | ldv) & 7 || (ldo & 3)) return fail(LDIT_EINVAL, "attention_bf16: row strides must be multiples of 8 (in) / 4 (out)");
     if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || (reinterpret_cast<uintptr_t>(O) & (OUT_FP8 ? 3u : 7u)))
         return fail(LDIT_EINVAL, "attention_bf16: operands must be 16-byte aligned");
-    static const bool kt4 = [] { const char *e = getenv("LDIT_ATTN_BF16_KT"); return e && *e == '4'; }();
+    const bool kt4 = diag().attn_bf16_kt4;
     constexpr int NW = 4;
     const int nqt = (N + 31) / 32, nqg = (nqt + NW - 1) / NW;
-    auto go = [&](auto kern, int lds, bool &attr_set) -> int {
-        if (!attr_set) {
-            LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_set = true;
-        }
+    auto go = [&](auto kern, int lds, std::atomic<unsigned long long> &attr_done) -> int {
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done)) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)(B * H * nqg)), dim3(NW * 64), lds, stream, static_cast<const bf16_t *>(Q),
                            static_cast<const bf16_t *>(K), static_cast<const bf16_t *>(V), O, N, H, ldq, ldk, ldv, ldo, scale, nqg,
                            qscale, lse);
@@ -314,7 +311,7 @@ static int launch_attn(const void *Q, const void *K, const void *V, void *O, int
     };
     // LDS = two stages of (K image + V image).  64-key chunks: 32 KB and 128 VGPRs -> four workgroups per CU (four waves per
     // SIMD), measured 8-10 % faster than 128-key chunks at two per CU (LDIT_ATTN_BF16_KT=4) on N = 197 and N = 1025.
-    static bool set2 = false, set4 = false;
+    static std::atomic<unsigned long long> set2{0}, set4{0};      // per-device bookkeeping (ensure_dynamic_lds)
     if (kt4) LDIT_TRY_RC(go(attention_bf16<4, NW, OUT_FP8>, 2 * 2 * 4 * 32 * KROWB, set4));
     else LDIT_TRY_RC(go(attention_bf16<2, NW, OUT_FP8>, 2 * 2 * 2 * 32 * KROWB, set2));
     LDIT_HIP_CHECK(hipGetLastError());

@@ -250,12 +250,7 @@ int launch_attention_bwd_bf16(const void *Q, const void *K, const void *V, const
         ((reinterpret_cast<uintptr_t>(dQ) | reinterpret_cast<uintptr_t>(dK) | reinterpret_cast<uintptr_t>(dV)) & 7u))
         return fail(LDIT_EINVAL, "attention_bwd: operands must be 16-byte (inputs) / 8-byte (outputs) aligned");
     const int NP = ((N + 31) / 32) * 32, lds = 4 * NP * ROWB + 2 * NP * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_bwd_bf16),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * ROWB + 2 * 256 * 4));
-        attr_set = true;
-    }
+    LDIT_DYN_LDS(attention_bwd_bf16, 4 * 256 * ROWB + 2 * 256 * 4);
     hipLaunchKernelGGL(attention_bwd_bf16, dim3((unsigned)(B * H)), dim3(512), lds, stream, static_cast<const bf16_t *>(Q),
                        static_cast<const bf16_t *>(K), static_cast<const bf16_t *>(V), static_cast<const bf16_t *>(O),
                        static_cast<const bf16_t *>(dO), lse, static_cast<bf16_t *>(dQ), static_cast<bf16_t *>(dK),

@@ -233,21 +233,19 @@ int launch_attention(const float *Q, const float *K, const float *V, float *O, i
     constexpr int KT = 7;
     constexpr int lds = KT * 32 * (KSTR + VSTR) * 4;
     const int nqt = (N + 31) / 32;
-    auto go = [&](auto kern, int nw, bool &attr_set) -> int {
-        if (!attr_set) {
-            LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_set = true;
-        }
+    auto go = [&](auto kern, int nw, std::atomic<unsigned long long> &attr_done) -> int {
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, attr_done)) return rc;
         const int nqg = (nqt + nw - 1) / nw;
         hipLaunchKernelGGL(kern, dim3((unsigned)(B * H * nqg)), dim3(nw * 64), lds, stream, Q, K, V, O, N, H, ldq, ldk, ldv, ldo,
                            scale, nqg);
+        LDIT_HIP_CHECK(hipGetLastError());
         return LDIT_OK;
     };
     // Eight query tiles per workgroup share one staging of the head's K and V - right when B*H workgroups fill the chip.
     // At serving sizes (one image = 12 workgroups, each a CU with two waves per SIMD queueing on one matrix pipe) the
     // query tiles are spread over twice the workgroups, one wave per SIMD: 34 -> 18 us at B = 1.  A query tile's arithmetic
     // does not depend on which workgroup computes it, so the results are bit-identical either way.
-    static bool set8 = false, set4 = false;
+    static std::atomic<unsigned long long> set8{0}, set4{0};      // per-device bookkeeping (ensure_dynamic_lds)
     const long wgs8 = (long)B * H * ((nqt + 7) / 8);
     if (wgs8 <= 128 && nqt > 4) { if (int rc = go(attention_f32<KT, 4>, 4, set4)) return rc; }
     else if (int rc = go(attention_f32<KT, 8>, 8, set8)) return rc;

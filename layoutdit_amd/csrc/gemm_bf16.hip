@@ -271,12 +271,7 @@ int launch_h(const GemmArgsH &a, hipStream_t stream)
     constexpr int lds = 2 * (BM + BN) * ROWB;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     auto kern = gemm_bf16_mfma<WM, WN, TM, TN, EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    LDIT_DYN_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3(tiles * a.x.splits), dim3(64 * WM * WN), lds, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
@@ -391,12 +386,7 @@ int launch_skinny(const GemmArgsH &a, hipStream_t stream)
 {
     constexpr int lds = 8 * 4096 * 4;
     auto kern = gemm_bf16_skinny<EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    LDIT_DYN_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((a.N + 63) / 64), dim3(512), lds, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
@@ -405,7 +395,7 @@ int launch_skinny(const GemmArgsH &a, hipStream_t stream)
 template <int EPI>
 int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
 {
-    if (a.M <= 64 && a.K % 128 == 0 && a.x.splits == 1 && !getenv("LDIT_GEMM_BF16_TILE")) return launch_skinny<EPI>(a, stream);
+    if (a.M <= 64 && a.K % 128 == 0 && a.x.splits == 1 && !diag().bf16_tile_env) return launch_skinny<EPI>(a, stream);
     // Time model fitted to scripts/gemm_bf16_bench.py on ViT-B / ViT-L shapes, M = 3 k .. 25 k (profiles/README.md), in us:
     //   256 x 256, 8 waves (one workgroup per CU):  strict rounds of 256 tiles, each  a[epi] + 19.5e-3 K
     //   128 x 128 (two per CU, they overlap each other's prologue / epilogue):  rounds of 256 tiles, each  r[epi] + 7.6e-3 K,
@@ -434,9 +424,7 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
         const double c = (double)((t + 255) / 256) * per256 * (bm / 256.0) * 1.03;      // 3 % handicap: prefer the fitted tiles on ties
         if (c < best) { best = c; pick = bm == 192 ? 4 : 5; }
     }
-    if (const char *force = getenv("LDIT_GEMM_BF16_TILE")) {
-        if (force[0] >= '2' && force[0] <= '5' && force[1] == 0) pick = force[0] - '0';
-    }
+    if (const int force = diag().bf16_tile; force >= 2 && force <= 5) pick = force;
     switch (pick) {
         case 3: return launch_h<2, 4, 4, 2, EPI>(a, stream);     // 256 x 256, 8 waves (2 per SIMD)
         case 4: return launch_h<2, 4, 3, 2, EPI>(a, stream);     // 192 x 256
@@ -510,8 +498,7 @@ static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const flo
     GemmArgsH a{};
     a.A = static_cast<const bf16_t *>(A); a.W = static_cast<const bf16_t *>(W); a.Y = Y; a.Y2 = Y2; a.bias = bias; a.lam = lam;
     a.R = R; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldy = ldy; a.x = x;
-    static const int direct = [] { const char *e = getenv("LDIT_GEMM_DIRECT_EPILOGUE"); return (e && *e == '1') ? 1 : 0; }();
-    a.direct_epi = direct;
+    a.direct_epi = diag().direct_epi ? 1 : 0;
     switch (epi) {
         case EPI_BIAS: return launch_h_tiled<EPI_BIAS>(a, stream);
         case EPI_BIAS_GELU: return launch_h_tiled<EPI_BIAS_GELU>(a, stream);

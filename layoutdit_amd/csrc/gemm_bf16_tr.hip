@@ -205,11 +205,7 @@ int launch_tr(const GemmArgsH &a, hipStream_t stream)
     static_assert(lds >= WM * WN * EPI_WAVE_BYTES, "epilogue slabs must fit the stage memory");
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     auto kern = gemm_bf16_tr<WM, WN, TM, TN, EPI, TA>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    LDIT_DYN_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3(tiles * a.x.splits), dim3(64 * WM * WN), lds, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
@@ -231,8 +227,7 @@ int launch_tr_tiled(const GemmArgsH &a, hipStream_t stream)
             if (c < best) { best = c; pick = bm == 192 ? 4 : 5; }
         }
     }
-    if (const char *force = getenv("LDIT_GEMM_BF16_TR_TILE"))
-        if (force[0] >= '2' && force[0] <= (TA ? '3' : '5') && force[1] == 0) pick = force[0] - '0';
+    if (const int force = diag().bf16_tr_tile; force >= 2 && force <= (TA ? 3 : 5)) pick = force;
     if constexpr (!TA) {
         if (pick == 4) return launch_tr<2, 4, 3, 2, EPI, TA>(a, stream);
         if (pick == 5) return launch_tr<2, 4, 5, 2, EPI, TA>(a, stream);

@@ -323,12 +323,7 @@ int launch_one(const GemmArgs &a, hipStream_t stream)
     constexpr int lds = 2 * (BM + BN) * ROW_BYTES;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     auto kern = gemm_f32_mfma<TM, TN, EPI, AMODE>;
-    static bool attr_set = false;   // benign race: idempotent attribute
-    if (!attr_set) {
-        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    LDIT_DYN_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
@@ -354,9 +349,7 @@ int launch_tiled(const GemmArgs &a, hipStream_t stream)
         const double cost = (double)rounds * c.bm * c.bn / c.eff;
         if (best < 0 || cost < best) { best = cost; pick = c.id; }
     }
-    if (const char *force = getenv("LDIT_GEMM_TILE")) {
-        if (force[0] >= '0' && force[0] <= '7' && force[0] != '4' && force[1] == 0) pick = force[0] - '0';
-    }
+    if (const int force = diag().gemm_tile; force >= 0 && force != 4) pick = force;
     if ((AMODE != A_ROWMAJOR || EPI == EPI_EMBED) && pick >= 5) pick = 3;
     if (AMODE == A_CONV3 && pick == 3) pick = 0;                      // the panel kernel has no implicit-im2col loader
     if (pick == 3) return launch_gemm_panel(a, EPI, AMODE, stream);   // 304 x 128 panel tiling (gemm_panel_f32.hip)
@@ -405,8 +398,8 @@ int launch_gemm(const GemmArgs &a, int epi, int amode, hipStream_t stream)
     // serving-size batches: the 32 x 32 / 16x16x4 kernel (same k order, bit-identical results; gemm_thin_f32.hip).
     // LDIT_GEMM_TILE=4 forces it for any M, 0..3 and 5..7 force one of the big tilings (tests cover every instantiation that way).
     {
-        const char *force = getenv("LDIT_GEMM_TILE");
-        const bool thin = force ? (force[0] == '4' && force[1] == 0) : gemm_thin_prefers(a.M, a.N);
+        const int force = diag().gemm_tile;
+        const bool thin = force >= 0 ? force == 4 : gemm_thin_prefers(a.M, a.N);
         if (thin && epi >= EPI_BIAS && epi <= EPI_SCALE_RESID) {
             if (epi == EPI_SCALE_RESID && (!a.lam || !a.R)) return fail(LDIT_EINVAL, "gemm: scale+residual epilogue needs lam and R");
             return launch_gemm_thin(a, epi, stream);

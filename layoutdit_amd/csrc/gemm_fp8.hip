@@ -289,12 +289,7 @@ int launch_q(const GemmArgs8 &a, hipStream_t stream)
     constexpr int lds = 2 * (BM + BN) * ROW8;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     auto kern = gemm_fp8_mfma<WM, WN, TM, TN, EPI, K64>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    LDIT_DYN_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WM * WN), lds, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
@@ -402,12 +397,7 @@ int launch_qskinny(const GemmArgs8 &a, hipStream_t stream)
 {
     constexpr int lds = 8 * 4096 * 4;
     auto kern = gemm_fp8_skinny<EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    LDIT_DYN_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((a.N + 63) / 64), dim3(512), lds, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
@@ -417,8 +407,7 @@ template <int EPI>
 int launch_q_tiled(const GemmArgs8 &a, hipStream_t stream)
 {
     // LDIT_GEMM_FP8_K16=1 selects the K = 16 MFMA, LDIT_GEMM_FP8_TILE=0..2 forces a tile (both for experiments / tests)
-    static const bool k16 = [] { const char *e = getenv("LDIT_GEMM_FP8_K16"); return e && *e == '1'; }();
-    static const bool noskinny = [] { const char *e = getenv("LDIT_GEMM_FP8_NOSKINNY"); return e && *e == '1'; }();
+    const bool k16 = diag().fp8_k16, noskinny = diag().fp8_noskinny;
     if (a.M <= 64 && !noskinny) return launch_qskinny<EPI>(a, stream);     // peeled tail / tiny batch: split-K
     // Time model fitted to scripts/gemm_fp8_bench.py on ViT-B / ViT-L shapes, M = 3 k .. 25 k (profiles/README.md), in us:
     //   256 x 256 (one workgroup per CU):  strict rounds of 256 tiles, each  a[epi] + 11.3e-3 K
@@ -439,8 +428,7 @@ int launch_q_tiled(const GemmArgs8 &a, hipStream_t stream)
         const double c = (double)((t + 255) / 256) * per256 * (bm / 256.0) * 1.03;
         if (c < best) { best = c; pick = bm == 192 ? 3 : 4; }
     }
-    if (const char *force = getenv("LDIT_GEMM_FP8_TILE"))
-        if (force[0] >= '0' && force[0] <= '4' && force[1] == 0) pick = force[0] - '0';
+    if (const int force = diag().fp8_tile; force >= 0 && force <= 4) pick = force;
     if (k16 && pick > 2) pick = 0;
     if (pick == 3) return launch_q<2, 4, 3, 2, EPI, true>(a, stream);      // 192 x 256
     if (pick == 4 && EPI == EPI_SCALE_RESID) pick = 0;
@@ -557,8 +545,7 @@ static int launch_gemm_fp8_one(const void *A, int lda, const void *W, const floa
     a.A = static_cast<const unsigned char *>(A); a.W = static_cast<const unsigned char *>(W); a.Y = Y; a.Y2 = Y2;
     a.bias = bias; a.lam = lam; a.R = R; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldy = ldy;
     a.ab_scale = ab_scale; a.out_inv_scale = out_inv_scale; a.d_act = d_act; a.d_wrow = d_wrow; a.d_out = d_out;
-    static const int direct = [] { const char *e = getenv("LDIT_GEMM_DIRECT_EPILOGUE"); return (e && *e == '1') ? 1 : 0; }();
-    a.direct_epi = direct;
+    a.direct_epi = diag().direct_epi ? 1 : 0;
     switch (epi) {
         case EPI_BIAS: return launch_q_tiled<EPI_BIAS>(a, stream);
         case EPI_BIAS_GELU: return launch_q_tiled<EPI_BIAS_GELU>(a, stream);

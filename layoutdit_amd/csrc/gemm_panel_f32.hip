@@ -418,7 +418,7 @@ int launch_panel(const GemmArgs &a, hipStream_t stream)
 {
     // LDIT_PANEL_R16=vec selects the conflict-free b128 remainder reads (see load_frags); the default scalar reads measured
     // 1.7 % faster (profiles/README.md, round 2: three interleaved A/B pairs on one device)
-    static const bool vec = [] { const char *e = getenv("LDIT_PANEL_R16"); return e && e[0] == 'v'; }();
+    const bool vec = diag().panel_r16_vec;
     return vec ? launch_panel_v<T32, HALF, EPI, AMODE, true>(a, stream) : launch_panel_v<T32, HALF, EPI, AMODE, false>(a, stream);
 }
 
@@ -429,12 +429,7 @@ int launch_panel_v(const GemmArgs &a, hipStream_t stream)
     constexpr int lds = 2 * NLD * 4 * 1024;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BNP - 1) / BNP);
     auto kern = gemm_panel_f32<T32, HALF, EPI, AMODE, R16VEC>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    LDIT_DYN_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;

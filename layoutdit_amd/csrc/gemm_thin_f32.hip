@@ -247,11 +247,7 @@ int launch_thin(const GemmArgs &a, hipStream_t stream)
     constexpr int lds = NS * STAGE;
     const int nbm = (a.M + TB - 1) / TB, nbn = (a.N + TB - 1) / TB;
     auto kern = gemm_thin_f32<EPI>;
-    static bool attr_set = false;   // benign race: idempotent attribute
-    if (!attr_set) {
-        LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    LDIT_DYN_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(nbm * ((nbn + 7) / 8) * 8)), dim3(256), lds, stream, a, nbm, nbn);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
@@ -265,8 +261,7 @@ int launch_thin(const GemmArgs &a, hipStream_t stream)
 // switches the kernel off.
 bool gemm_thin_prefers(int M, int N)
 {
-    long limit = 192;
-    if (const char *e = getenv("LDIT_GEMM_THIN_TILES")) limit = atol(e);
+    const long limit = diag().thin_tiles;
     return (long)((M + 63) / 64) * ((N + 63) / 64) <= limit;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -25,6 +26,36 @@ int fail(int code, const char *fmt, ...);
     } while (0)
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): a process that drives several GPUs must set it
+// on each of them before the first launch there with more than 64 KB of dynamic LDS.  `done` (one per kernel instantiation,
+// a function-local static of its launcher) holds one bit per device ordinal; ordinals >= 64 set the attribute every time.
+// The attribute is idempotent, so two threads racing on the same bit at worst both set it.  This is the library's only
+// mutable process state besides the diagnostic switches below.
+int ensure_dynamic_lds(const void *kern, int bytes, std::atomic<unsigned long long> &done);
+#define LDIT_DYN_LDS(kern, bytes)                                                                               \
+    do {                                                                                                        \
+        static std::atomic<unsigned long long> done__{0};                                                       \
+        if (int rc__ = ::ldit::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (bytes), done__)) return rc__; \
+    } while (0)
+
+// Diagnostic switches (tests and experiments force every tiling through them; none is needed in production).  Read from the
+// environment ONCE, when the library is first used - not per launch (a getenv on the 12 us-per-launch serving path) - and
+// again only by ldit_debug_reload_env() (tests call it after changing a variable).
+struct DiagSwitches {
+    int gemm_tile = -1;          // LDIT_GEMM_TILE 0..7 (fp32 GEMM tiling)
+    long thin_tiles = 192;       // LDIT_GEMM_THIN_TILES
+    bool panel_r16_vec = false;  // LDIT_PANEL_R16=vec
+    int bf16_tile = -1;          // LDIT_GEMM_BF16_TILE 2..5 (-1 = picker; any value also disables the small-M kernel)
+    bool bf16_tile_env = false;  //   the variable is present at all
+    int bf16_tr_tile = -1;       // LDIT_GEMM_BF16_TR_TILE
+    int fp8_tile = -1;           // LDIT_GEMM_FP8_TILE 0..4
+    bool fp8_k16 = false, fp8_noskinny = false;   // LDIT_GEMM_FP8_K16, LDIT_GEMM_FP8_NOSKINNY
+    bool direct_epi = false;     // LDIT_GEMM_DIRECT_EPILOGUE=1
+    bool attn_bf16_kt4 = false;  // LDIT_ATTN_BF16_KT=4
+};
+const DiagSwitches &diag();
+void reload_diag();
 
 // erf to < 1 ulp in ~25 instructions, branch-free (both ranges evaluated, one selected): odd polynomial in x below
 // 0.927734375, 1 - exp(poly(|x|)) above (coefficients: N. Juffa's single-precision erff).  libdevice's erff costs

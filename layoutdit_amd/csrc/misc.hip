@@ -158,13 +158,11 @@ int launch_tiled_maps(const float *tap, float *out, int B, int Gh, int Gw, int C
     const bool vec = (Ow % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
     if (vec) {
         auto kern = tap_to_map_tiled<CB, 4>;
-        static bool attr_set = false;
-        if (!attr_set) { LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_set = true; }
+        LDIT_DYN_LDS(kern, 65536);
         hipLaunchKernelGGL(kern, grid, block, lds, stream, tap, out, Gh, Gw, C, Oh, Ow, 1.0f / scale);
     } else {
         auto kern = tap_to_map_tiled<CB, 1>;
-        static bool attr_set = false;
-        if (!attr_set) { LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr_set = true; }
+        LDIT_DYN_LDS(kern, 65536);
         hipLaunchKernelGGL(kern, grid, block, lds, stream, tap, out, Gh, Gw, C, Oh, Ow, 1.0f / scale);
     }
     LDIT_HIP_CHECK(hipGetLastError());

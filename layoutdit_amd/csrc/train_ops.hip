@@ -566,12 +566,7 @@ int launch_layernorm_bwd(const float *dy, const float *x, const float *g, float 
     else if (C <= 768) LAUNCH_CHECKED((layernorm_bwd_rows<3, 8>), dim3(blocks), dim3(512), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
     else if (C <= 1024) LAUNCH_CHECKED((layernorm_bwd_rows<4, 8>), dim3(blocks), dim3(512), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
     else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            LDIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(layernorm_bwd_rows<16, 4>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 4096 * 4));
-            attr_set = true;
-        }
+        LDIT_DYN_LDS((layernorm_bwd_rows<16, 4>), 2 * 4 * 4096 * 4);
         LAUNCH_CHECKED((layernorm_bwd_rows<16, 4>), dim3(blocks), dim3(256), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
     }
     return LDIT_OK;

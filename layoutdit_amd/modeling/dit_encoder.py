@@ -55,10 +55,17 @@ class DiTEncoderOutput:
 
 class DiTEncoder(nn.Module):
     def __init__(self, config: Optional[DiTConfig] = None, compute_dtype: str = "f32"):
-        """``compute_dtype``: ``"f32"`` (exact-fp32 MFMA, the parity path), ``"bf16"`` (bf16 GEMM / attention operands
-        with fp32 accumulation, residual stream, LayerNorm and softmax; parameters and returned taps stay fp32) or
-        ``"fp8"`` (the four GEMMs of a layer on fp8 e4m3 operands with per-tensor scales, attention on bf16; needs one
-        ``calibrate_fp8(sample_batch)`` call before the first forward)."""
+        """``compute_dtype``: arithmetic of the INFERENCE forward - ``"f32"`` (exact-fp32 MFMA, the parity path), ``"bf16"``
+        (bf16 GEMM / attention operands with fp32 accumulation, residual stream, LayerNorm and softmax; parameters and
+        returned taps stay fp32) or ``"fp8"`` (the four GEMMs of a layer on fp8 e4m3 operands with per-tensor scales,
+        attention on bf16; needs one ``calibrate_fp8(sample_batch)`` call before the first forward).
+
+        TRAINING (``.train()`` + ``loss.backward()``, ref trainer.py:168-180) is mixed precision for the ``"f32"`` and
+        ``"bf16"`` builds alike: bf16 MFMA operands, fp32 accumulation, fp32 residual stream / LayerNorm / softmax /
+        gradients / master parameters - what the reference's CUDA branch does with fp16 autocast + GradScaler
+        (trainer.py:168,177-180; bf16 needs no loss scaling, a scaled loss passes through unharmed) and within the
+        bf16 gate of its fp32 CPU branch (trainer.py:171-172; gradients rel-L2 <= 3e-2 per tensor, measured <= 1e-2:
+        tests/test_gpu_train.py).  The ``"fp8"`` build is inference only."""
         super().__init__()
         if compute_dtype not in _DTYPES:
             raise ValueError(f"compute_dtype {compute_dtype!r}: expected 'f32', 'bf16' or 'fp8'")
@@ -131,6 +138,17 @@ class DiTEncoder(nn.Module):
         sd = {k: torch.from_numpy(v.copy()) for k, v in weights.items()}
         self.load_state_dict(sd, strict=True)
         return self
+
+    def mark_parameters_changed(self) -> None:
+        """Invalidate every cached copy of the parameters (the packed inference block, resampled position tables, the bf16
+        mirror of the training state).  The caches are keyed on autograd's version counters, which writes through
+        ``p.data`` (``p.data.copy_()`` / ``p.data.mul_()``, EMA-style code) and foreign kernels do not move: call this
+        after such a write.  ``load_state_dict``, ``p.copy_()`` and optimizers need no call."""
+        self._packed_key = None
+        self._pos_cache.clear()
+        st = getattr(self, "_flat_state", None)
+        if st is not None:
+            st.mark_dirty()
 
     # ---- packing / scratch -------------------------------------------------------------------------------------------
     def _lcfg(self, img_h: int, img_w: int, taps: Sequence[int]) -> _lib.LditCfg:
@@ -271,11 +289,9 @@ class DiTEncoder(nn.Module):
         ``layoutdit_amd.training`` (C ABI: ldit_vit_forward_train / ldit_vit_backward).  bf16 build only."""
         from .. import training
         cfg = self.config
-        if self.compute_dtype != "bf16":
-            raise NotImplementedError("training (backward through the encoder) exists for compute_dtype='bf16' only "
-                                      "(BASELINE configs[2]); freeze the backbone as the reference's commented option does "
-                                      "(dit_backbone.py:74-76), run under torch.no_grad() / .eval(), or build "
-                                      "DiTEncoder(..., compute_dtype='bf16')")
+        if self.compute_dtype == "fp8":
+            raise NotImplementedError("the fp8 build is inference only: train a DiTEncoder(..., compute_dtype='bf16' or 'f32') "
+                                      "(both train on bf16 MFMA operands with fp32 master parameters), or call .eval()")
         x = self._pixels_f32(pixel_values)
         L = cfg.num_hidden_layers
         drop = None
@@ -287,13 +303,32 @@ class DiTEncoder(nn.Module):
             st = training.flat_state(self, x.shape[2], x.shape[3])
             st.repack()
             with torch.no_grad():
-                outs = st.forward(x, taps, drop, st.new_saved(x.shape[0]))
+                outs = st.forward(x, taps, drop, st.saved_nograd(x.shape[0]))
         hidden: List[Optional[torch.Tensor]] = [None] * (L + 1)
         for t, o in zip(taps, outs):
             hidden[t] = o
         if pixel_values.dtype != torch.float32 and not wants_grad:
             hidden = self._like_input(hidden, pixel_values.dtype)
         return DiTEncoderOutput(hidden_states=tuple(hidden), last_hidden_state=hidden[L])
+
+    def _train_forward_applies(self, H: int, W: int) -> bool:
+        """Train mode WITHOUT gradients (``model.train()`` under ``torch.no_grad()``): HF still applies stochastic depth
+        (TF:360-378), which only the training forward implements.  With a drop-path rate of 0 (or one layer) train and
+        eval arithmetic coincide and the inference kernels of ``compute_dtype`` run; otherwise the training forward runs
+        where its geometry allows (the position table's own grid, at most 256 tokens) and anything else is refused
+        rather than silently computed without stochastic depth."""
+        cfg = self.config
+        if cfg.drop_path_rate <= 0.0 or cfg.num_hidden_layers < 2:
+            return False
+        if self.compute_dtype == "fp8":
+            raise NotImplementedError("train mode with stochastic depth on the fp8 (inference-only) build: call .eval()")
+        g0 = cfg.image_size // cfg.patch_size
+        gh, gw = H // cfg.patch_size, W // cfg.patch_size
+        if (gh, gw) != (g0, g0) or gh * gw + 1 > 256:
+            raise NotImplementedError(f"train mode with stochastic depth (drop_path_rate={cfg.drop_path_rate}) at a "
+                                      f"{gh}x{gw} grid: the training forward covers the position table's own grid with at most "
+                                      "256 tokens; call .eval() for inference at other sizes")
+        return True
 
     # ---- forward -------------------------------------------------------------------------------------------------
     def forward(self, pixel_values: torch.Tensor, taps: Optional[Sequence[int]] = None,
@@ -317,7 +352,7 @@ class DiTEncoder(nn.Module):
             raise ValueError(f"at most {_lib.LDIT_MAX_TAPS} hidden states per call")
         device = pixel_values.device
         wants_grad = torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())
-        if self.training and (wants_grad or self.compute_dtype == "bf16"):
+        if self.training and (wants_grad or self._train_forward_applies(H, W)):
             return self._forward_train(pixel_values, taps, wants_grad)
         x = self._pixels_f32(pixel_values)
         with torch.no_grad(), torch.cuda.device(device):

@@ -106,7 +106,9 @@ class FlatState:
         # scratch of the library, sized once per batch size
         self.packed = torch.empty(lib.ldit_train_mirror_bytes(C.byref(self.lcfg)), dtype=torch.uint8, device=self.device)   # bf16 mirror
         self._packed_version = None
+        self._dirty = True
         self._ws: Dict[int, torch.Tensor] = {}
+        self._saved_nograd: Optional[Tuple[int, torch.Tensor]] = None
 
     # ---- bookkeeping ---------------------------------------------------------------------------------------------------
     def intact(self) -> bool:
@@ -129,14 +131,29 @@ class FlatState:
     def version(self):
         return tuple(p._version for _, p, _, _ in self.named)
 
+    def mark_dirty(self) -> None:
+        """Tell the state that the flat block was written behind autograd's version counters (``p.data.copy_()``,
+        ``p.data.mul_()``, EMA-style code, a foreign kernel): the next :meth:`repack` rebuilds the bf16 mirror.  Writes through
+        the parameters themselves (``p.copy_()``, optimizers) bump ``p._version`` and need no call."""
+        self._dirty = True
+
     def repack(self, force: bool = False) -> None:
-        """flat fp32 parameters -> their bf16 mirror (one pass), when a parameter's version changed."""
+        """flat fp32 parameters -> their bf16 mirror (one pass), when a parameter's version changed, after
+        :meth:`mark_dirty`, or with ``force=True``.  ``.data`` writes bypass the version counter: call ``mark_dirty()``."""
         v = self.version()
-        if force or v != self._packed_version:
+        if force or self._dirty or v != self._packed_version:
             with torch.cuda.device(self.device):
                 _lib.check(_lib.load().ldit_pack_train(C.byref(self.lcfg), self.params.data_ptr(), self.packed.data_ptr(),
                                                        self.packed.numel(), torch.cuda.current_stream(self.device).cuda_stream))
             self._packed_version = v
+            self._dirty = False
+
+    def saved_nograd(self, batch: int) -> torch.Tensor:
+        """One reusable activation block per batch size for forwards that never run a backward (train mode under no_grad)."""
+        if self._saved_nograd is None or self._saved_nograd[0] != batch:
+            self._saved_nograd = None
+            self._saved_nograd = (batch, self.new_saved(batch))
+        return self._saved_nograd[1]
 
     def workspace(self, batch: int) -> torch.Tensor:
         ws = self._ws.get(batch)
@@ -232,12 +249,30 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dtaps):
         st: FlatState = ctx.state
+        if ctx.saved_acts is None:
+            raise RuntimeError("DiTEncoder: trying to backward through the encoder a second time - its saved activations "
+                               "(several GB) are freed after the first backward and retain_graph=True is not supported; "
+                               "run the forward again")
         d = [None if g is None else g.contiguous().to(torch.float32) for g in dtaps]
         L = st.lcfg.layers
         st.backward(ctx.x, ctx.taps, d, ctx.drop, ctx.saved_acts, L, 0)
-        grads = tuple(st.grad_view(off, shape).clone() for _, _, off, shape in st.named)
         ctx.saved_acts = None
+        need = ctx.needs_input_grad[4:]
+        if not any(need):
+            return (None,) * (4 + len(st.named))
+        # ONE copy of the flat gradient block (the library overwrites it on the next backward); the per-parameter gradients
+        # handed to autograd are views of that copy
+        flat = st.grads.clone()
+        grads = tuple(flat[off: off + _numel(shape)].view(shape) if n else None
+                      for (_, _, off, shape), n in zip(st.named, need))
         return (None, None, None, None) + grads
+
+
+def _numel(shape) -> int:
+    n = 1
+    for v in shape:
+        n *= v
+    return n
 
 
 def encoder_forward_autograd(encoder, x: torch.Tensor, taps: Sequence[int], drop_scales: Optional[torch.Tensor] = None):
@@ -257,8 +292,9 @@ class TrainStep:
                  dtaps: Optional[Sequence[torch.Tensor]] = None, drop_path_rate: Optional[float] = None,
                  img_size: Optional[Tuple[int, int]] = None, force_comm: bool = False):
         cfg = encoder.config
-        if encoder.compute_dtype != "bf16":
-            raise NotImplementedError("the train step exists for compute_dtype='bf16' only (BASELINE configs[2])")
+        if encoder.compute_dtype == "fp8":
+            raise NotImplementedError("the fp8 build is inference only; the train step runs the 'bf16' and 'f32' builds on bf16 "
+                                      "MFMA operands with fp32 master parameters (BASELINE configs[2])")
         h, w = img_size or (cfg.image_size, cfg.image_size)
         self.encoder, self.rank = encoder, rank
         self.state = flat_state(encoder, h, w)
@@ -335,5 +371,8 @@ class TrainStep:
                                                    self.eps, self.wd, self.steps, 1.0 / self.world, st.packed.data_ptr(),
                                                    torch.cuda.current_stream(st.device).cuda_stream))
         st._packed_version = st.version()     # the update refreshed the bf16 mirror itself
-        self.encoder._packed_key = None       # the eval path's packed copy (DiTEncoder._pack) is stale now
+        st._dirty = False
+        # the update went through raw pointers: no tensor version moved, so every cache keyed on versions is stale now
+        self.encoder._packed_key = None       # the eval path's packed copy (DiTEncoder._pack)
+        self.encoder._pos_cache.clear()       # bicubic resamples of the position table for other grids (_position_table)
         return taps

@@ -28,15 +28,14 @@ for M, C in ((64 * 197, 768), (32 * 197, 768), (16 * 1025, 1024)):
         res = {t: [] for t in TILES}
         for rnd in range(5):
             for t in res:
-                if t == "auto": os.environ.pop(ENV, None)
-                else: os.environ[ENV] = t
+                _lib.set_switch(ENV, None if t == "auto" else t)
                 for _ in range(3): run(x, w, b, **kw)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(20): run(x, w, b, **kw)
                 e1.record(); torch.cuda.synchronize()
                 res[t].append(e0.elapsed_time(e1) / 20 * 1e3)
-        os.environ.pop(ENV, None)
+        _lib.set_switch(ENV, None)
         med = {t: statistics.median(v) for t, v in res.items()}
         fl = 2.0 * m * n * k
         print(f"M={m:6d} {name:7s} N={n:5d} K={k:5d}  " + "  ".join(f"{t}:{med[t]:7.1f}us" for t in res) +

@@ -4,7 +4,7 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from layoutdit_amd import ops  # noqa: E402
+from layoutdit_amd import _lib, ops  # noqa: E402
 
 dev = "cuda:0"
 shapes = [(197, 2304, 768), (197, 768, 768), (197, 3072, 768), (197, 768, 3072)]
@@ -19,7 +19,7 @@ for B in Bs:
         y = torch.empty(M, N, device=dev)
         line = f"M={M:5d} N={N:5d} K={K:5d}:"
         for tile in ("4", "2"):
-            os.environ["LDIT_GEMM_TILE"] = tile
+            _lib.set_switch("LDIT_GEMM_TILE", tile)
             for mode in ("warm", "cold"):
                 reps = 40
                 for i in range(5):

@@ -14,7 +14,9 @@ differentiated with `torch.autograd` for upstream gradients `dtaps` drawn from t
   * train mode (`model.train()`, `drop_path_rate = 0.1`): the per-sample stochastic-depth factors HF actually applied are
     CAPTURED with forward hooks on its `BeitDropPath` modules and stored next to the gradients (DATA: 0 or 1/keep_prob
     per layer, branch and sample), so the build can replay exactly the same masks.
-Outputs (data only): g6_grad_micro.npz (every third element of every gradient), g7_grad_tiny.npz (strided samples + norms).
+Outputs (data only): g6_grad_micro.npz (every third element of every gradient), g7_grad_tiny.npz (strided samples + norms),
+g8_grad_base.npz (ViT-B/16 224x224 bs=2 - the geometry of BASELINE.json configs[2] itself; strided samples + norms).
+`python tests/golden/make_golden_grad.py g8` regenerates one file only.
 """
 import os
 import sys
@@ -124,8 +126,14 @@ def emit(name, cfg, B, size, wseed, xseed, gseed, stride):
 
 
 def main():
-    emit("g6_grad_micro.npz", cfgs.vit_micro(), 4, 64, wseed=7, xseed=99, gseed=5, stride=3)
-    emit("g7_grad_tiny.npz", cfgs.vit_tiny(), 2, 224, wseed=1, xseed=1234, gseed=6, stride=53)
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    if only in ("", "g6"):
+        emit("g6_grad_micro.npz", cfgs.vit_micro(), 4, 64, wseed=7, xseed=99, gseed=5, stride=3)
+    if only in ("", "g7"):
+        emit("g7_grad_tiny.npz", cfgs.vit_tiny(), 2, 224, wseed=1, xseed=1234, gseed=6, stride=53)
+    if only in ("", "g8"):
+        # configs[2]'s own geometry (C = 768, 12 heads, F = 3072); the same weight / image seeds as g2_base.npz
+        emit("g8_grad_base.npz", cfgs.vit_base(), 2, 224, wseed=0, xseed=1234, gseed=8, stride=499)
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@ def _bf16_round(a):
 def _cleanup():
     _lib.load()
     yield
-    os.environ.pop("LDIT_GEMM_BF16_TILE", None)
+    _lib.set_switch("LDIT_GEMM_BF16_TILE", None)
 
 
 def test_cast_matches_torch_round_to_nearest_even():
@@ -44,7 +44,7 @@ def test_cast_matches_torch_round_to_nearest_even():
 @pytest.mark.parametrize("M,N,K", [(37, 50, 64), (394, 576, 192), (1025, 1024, 1024), (513, 3072, 768), (300, 768, 4096)])
 def test_linear_bf16_bias(M, N, K, tile):
     if tile != "auto":
-        os.environ["LDIT_GEMM_BF16_TILE"] = tile
+        _lib.set_switch("LDIT_GEMM_BF16_TILE", tile)
     x, w, b = _bf16_round(_rand(1, M, K)), _bf16_round(_rand(2, N, K, scale=0.05)), _rand(3, N, scale=0.1)
     xd, wd = torch.from_numpy(x).to(DEV).to(torch.bfloat16), torch.from_numpy(w).to(DEV).to(torch.bfloat16)
     y = ops.linear_bf16(xd, wd, torch.from_numpy(b).to(DEV)).float().cpu().numpy()
@@ -55,7 +55,7 @@ def test_linear_bf16_bias(M, N, K, tile):
 
 @pytest.mark.parametrize("tile", ["1", "2", "3", "4", "5"])
 def test_linear_bf16_gelu_and_residual(tile):
-    os.environ["LDIT_GEMM_BF16_TILE"] = tile
+    _lib.set_switch("LDIT_GEMM_BF16_TILE", tile)
     M, N, K = 394, 320, 128
     x, w, b = _bf16_round(_rand(4, M, K)), _bf16_round(_rand(5, N, K, scale=0.2)), _rand(6, N)
     xd, wd, bd = (torch.from_numpy(x).to(DEV).to(torch.bfloat16), torch.from_numpy(w).to(DEV).to(torch.bfloat16),

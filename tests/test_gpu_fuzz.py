@@ -37,15 +37,15 @@ def _cases(n, seed):
 def _cleanup():
     _lib.load()
     yield
-    os.environ.pop("LDIT_GEMM_TILE", None)
-    os.environ.pop("LDIT_GEMM_BF16_TILE", None)
-    os.environ.pop("LDIT_GEMM_FP8_TILE", None)
+    _lib.set_switch("LDIT_GEMM_TILE", None)
+    _lib.set_switch("LDIT_GEMM_BF16_TILE", None)
+    _lib.set_switch("LDIT_GEMM_FP8_TILE", None)
 
 
 @pytest.mark.parametrize("tile", ["auto", "0", "1", "2", "3", "4", "5", "6", "7"])
 def test_fuzz_linear_f32(tile):
     if tile != "auto":
-        os.environ["LDIT_GEMM_TILE"] = tile
+        _lib.set_switch("LDIT_GEMM_TILE", tile)
     for idx, (M, N, K) in enumerate(_cases(14, 100 + len(tile))):
         epi = idx % 3
         x, w, b = _rand(idx, M, K), _rand(idx + 50, N, K, scale=0.1), _rand(idx + 90, N, scale=0.2)
@@ -67,7 +67,7 @@ def test_fuzz_linear_f32(tile):
 @pytest.mark.parametrize("tile", ["auto", "1", "2", "3", "4", "5"])
 def test_fuzz_linear_bf16(tile):
     if tile != "auto":
-        os.environ["LDIT_GEMM_BF16_TILE"] = tile
+        _lib.set_switch("LDIT_GEMM_BF16_TILE", tile)
     for idx, (M, N, K) in enumerate(_cases(10, 200 + len(tile))):
         K = 64 * ((K + 63) // 64)
         epi = idx % 3
@@ -90,7 +90,7 @@ def test_fuzz_linear_bf16(tile):
 def test_fuzz_linear_fp8(tile):
     """fp8 GEMM on the same ragged shapes; reference = oracle on the dequantised codes (gates: tests/test_gpu_fp8.py)."""
     if tile != "auto":
-        os.environ["LDIT_GEMM_FP8_TILE"] = tile
+        _lib.set_switch("LDIT_GEMM_FP8_TILE", tile)
     F8 = torch.float8_e4m3fn
     for idx, (M, N, K) in enumerate(_cases(10, 500 + len(tile))):
         K = 128 * ((K + 127) // 128)

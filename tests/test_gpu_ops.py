@@ -34,7 +34,7 @@ def _need_gpu():
     assert torch.cuda.is_available(), "gpu-marked test running without a GPU"
     _lib.load()
     yield
-    os.environ.pop("LDIT_GEMM_TILE", None)
+    _lib.set_switch("LDIT_GEMM_TILE", None)
 
 
 # ---------------------------------------------------------------------------------------------------------- GEMM
@@ -52,7 +52,7 @@ GEMM_SHAPES = [
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_linear_bias(M, N, K, tile):
     if tile != "auto":
-        os.environ["LDIT_GEMM_TILE"] = tile
+        _lib.set_switch("LDIT_GEMM_TILE", tile)
     x, w, b = _rand(1, M, K), _rand(2, N, K, scale=0.05), _rand(3, N, scale=0.1)
     y = ops.linear(_dev(x), _dev(w), _dev(b)).cpu().numpy()
     ref = oracle.linear(x, w, b)
@@ -81,7 +81,7 @@ def test_linear_identity_asymmetric():
 
 @pytest.mark.parametrize("tile", ["0", "1", "2", "3", "4", "5", "6", "7"])
 def test_linear_gelu_epilogue(tile):
-    os.environ["LDIT_GEMM_TILE"] = tile
+    _lib.set_switch("LDIT_GEMM_TILE", tile)
     M, N, K = 333, 320, 96
     x, w, b = _rand(6, M, K), _rand(7, N, K, scale=0.2), _rand(8, N)
     y = ops.linear(_dev(x), _dev(w), _dev(b), epilogue=_lib.EPI_BIAS_GELU).cpu().numpy()
@@ -92,7 +92,7 @@ def test_linear_gelu_epilogue(tile):
 @pytest.mark.parametrize("tile", ["0", "1", "2", "3", "4", "5", "6", "7"])
 def test_linear_scale_residual_inplace_and_tap(tile):
     """h <- h + lam * (x W^T + b), updated IN PLACE (R aliases Y) with a second copy to the tap buffer."""
-    os.environ["LDIT_GEMM_TILE"] = tile
+    _lib.set_switch("LDIT_GEMM_TILE", tile)
     M, N, K = 197 * 2, 192, 768
     x, w, b = _rand(9, M, K), _rand(10, N, K, scale=0.05), _rand(11, N, scale=0.1)
     lam, r = np.abs(_rand(12, N)) * 0.3 + 0.05, _rand(13, M, N)
@@ -116,7 +116,7 @@ def test_thin_tiling_is_bit_identical_to_the_big_tilings(M, N, K):
     lam, r = np.abs(_rand(24, N)) * 0.3 + 0.05, _rand(25, M, N)
     outs = {}
     for tile in ("4", "2", "3", "5", "6", "7"):
-        os.environ["LDIT_GEMM_TILE"] = tile
+        _lib.set_switch("LDIT_GEMM_TILE", tile)
         y0 = ops.linear(_dev(x), _dev(w), _dev(b))
         y1 = ops.linear(_dev(x), _dev(w), _dev(b), epilogue=_lib.EPI_BIAS_GELU)
         h = _dev(r)
@@ -126,7 +126,7 @@ def test_thin_tiling_is_bit_identical_to_the_big_tilings(M, N, K):
     for other in ("2", "3", "5", "6", "7"):
         for got, want in zip(outs["4"], outs[other]):
             np.testing.assert_array_equal(got, want)
-    os.environ.pop("LDIT_GEMM_TILE")
+    _lib.set_switch("LDIT_GEMM_TILE", None)
     auto = ops.linear(_dev(x), _dev(w), _dev(b)).cpu().numpy()          # whichever tiling the default picks, the bits are the same
     np.testing.assert_array_equal(auto, outs["4"][0])
 
@@ -136,7 +136,7 @@ def test_linear_row_strides_through_the_c_abi(tile):
     """lda > K and ldy > N (operands that are column slices of wider buffers: the fused q|k|v tensor, an output written into
     a slice of a concatenated map) on every fp32 tiling; the columns outside the slice must stay untouched."""
     if tile != "auto":
-        os.environ["LDIT_GEMM_TILE"] = tile
+        _lib.set_switch("LDIT_GEMM_TILE", tile)
     lib = _lib.load()
     M, N, K, lda, ldy = 211, 96, 64, 160, 224
     xw = _rand(31, M, lda)

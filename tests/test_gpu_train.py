@@ -232,7 +232,7 @@ def _grads_through_autograd(cfg, w, x, dtaps, scales, monkeypatch):
     return taps, grads, m
 
 
-@pytest.mark.parametrize("name,geom", [("g6_grad_micro.npz", "micro"), ("g7_grad_tiny.npz", "tiny")])
+@pytest.mark.parametrize("name,geom", [("g6_grad_micro.npz", "micro"), ("g7_grad_tiny.npz", "tiny"), ("g8_grad_base.npz", "base")])
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_parameter_gradients_vs_oracle_and_hf_golden(golden_dir, monkeypatch, name, geom, mode):
     g = np.load(os.path.join(golden_dir, name))
@@ -263,6 +263,82 @@ def test_parameter_gradients_vs_oracle_and_hf_golden(golden_dir, monkeypatch, na
     with open(f"gpurun_out/grad_parity_{geom}_{mode}.txt", "w") as f:
         for k, e in sorted(worst.items(), key=lambda kv: -kv[1]):
             f.write(f"{k:40s} {e:.3e}\n")
+
+
+def test_config2_full_size_train_step_vs_hf_golden_and_properties(golden_dir):
+    """BASELINE configs[2] at its OWN geometry and batch: ViT-B/16 224x224 bs=64 bf16, forward + backward + fused AdamW
+    (ref trainer.py:148-187 on self.dit).  An oracle run of 64 images is minutes of CPU time, so the full batch is pinned
+    through properties of the domain:
+      * linearity of the loss in the upstream gradients: with d loss / d taps zero for images 2..63, every parameter gradient
+        of the 64-image step is the gradient of the 2-image problem of tests/golden/g8_grad_base.npz - compared directly with
+        HF BeitModel's gradients (eval arithmetic; 62 more images ride through every GEMM, attention and reduction);
+      * batch invariance: taps of images 0..1 equal the bs=2 run bit for bit;
+      * the backward is bit-reproducible (no atomics) with generic upstream gradients on all 64 images;
+      * one fused AdamW step equals torch.optim.AdamW on the whole flat block, and its bf16 mirror is the rounded block."""
+    g = np.load(os.path.join(golden_dir, "g8_grad_base.npz"))
+    cfg = cfgs.vit_base()
+    wseed, xseed, gseed = (int(v) for v in g["seeds"])
+    B = 64
+    w = synth.synth_weights(cfg, wseed)
+    x = torch.from_numpy(synth.synth_images(B, 224, 224, seed=xseed, kind="doc")).to(DEV)
+    N, Cc, L = cfg.tokens(224, 224), cfg.hidden_size, cfg.num_hidden_layers
+    m = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(w).to(DEV).train()
+    m.config.drop_path_rate = 0.0
+    st = training.flat_state(m, 224, 224)
+    st.repack()
+    saved = st.new_saved(B)
+    # -- 1. linearity: upstream gradients on images 0..1 only = the golden's own problem
+    d2 = upstream(cfg, 2, N, gseed)
+    dt = []
+    for d in d2:
+        t = torch.zeros((B, N, Cc), device=DEV)
+        t[:2] = torch.from_numpy(d).to(DEV)
+        dt.append(t)
+    taps64 = st.forward(x, cfg.taps, None, saved)
+    st.backward(x, cfg.taps, dt, None, saved, L, 0)
+    torch.cuda.synchronize()
+    stride = int(g["stride"][0])
+    worst = 0.0
+    for name, p, off, shape in st.named:
+        k = _hf_name(name)
+        got = st.grad_view(off, shape).cpu().numpy()
+        e = rel_l2(got.reshape(-1)[::stride], g[f"eval_grad/{k}"])
+        worst = max(worst, e)
+        assert e < GRAD_TOL, (k, e, "bs=64 step vs HF golden of its first two images")
+    # -- 2. batch invariance of the training forward
+    saved2 = st.new_saved(2)
+    taps2 = st.forward(x[:2].contiguous(), cfg.taps, None, saved2)
+    for a, b, t in zip(taps64, taps2, cfg.taps):
+        assert torch.equal(a[:2], b), t
+        assert rel_l2(b.cpu().numpy().reshape(-1)[::max(stride, 7)], g[f"eval_tap{t}_sample"]) < 2e-2
+    del saved2
+    # -- 3. generic upstream gradients on every image, stochastic depth on: rerun-bit-equal backward
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(5)
+    dt = [torch.randn((B, N, Cc), device=DEV, generator=gen) / (B * N * Cc) ** 0.5 for _ in cfg.taps]
+    drop = training.sample_drop_scales(L, B, 0.1, DEV, gen)
+    assert bool((drop == 0).any())
+    step = training.TrainStep(m, lr=1e-4, weight_decay=0.0, dtaps=dt, drop_path_rate=0.1)
+    st.forward(x, cfg.taps, drop, saved)
+    st.backward(x, cfg.taps, dt, drop, saved, L, 0)
+    g1 = st.grads.clone()
+    assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    p0 = st.params.clone()
+    # -- 4. the fused step (same inputs): same gradients, AdamW == torch.optim.AdamW, mirror == rounded parameters
+    step.step(x, drop_scales=drop)
+    torch.cuda.synchronize()
+    assert torch.equal(st.grads, g1)
+    ref = torch.nn.Parameter(p0.clone())
+    ref.grad = g1.clone()
+    torch.optim.AdamW([ref], lr=1e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8).step()
+    diff = (st.params - ref.detach()).abs()
+    assert float(diff.max()) <= 2.0 ** -22 * max(1.0, float(p0.abs().max()))        # <= 2 ulp of the largest parameter
+    assert float((st.params - p0).abs().max()) > 5e-5                                # a first Adam step moves ~lr
+    mirror = st.packed.view(BF)[: st.numel]
+    assert torch.equal(mirror, st.params.to(BF))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/grad_parity_base_bs64.txt", "w") as f:
+        f.write(f"worst per-tensor rel-L2 vs HF golden (strided): {worst:.3e}\n")
 
 
 def test_key_bias_slot_and_reproducibility(monkeypatch):
@@ -346,9 +422,88 @@ def test_train_mode_without_grad_applies_stochastic_depth(monkeypatch):
     ref, _ = train_reference(cfg, w, x, [np.zeros((4, 17, 128), np.float32)] * 4, drop_scales=scales)
     for t, r in zip(cfg.taps, ref):
         assert rel_l2(hs[t].cpu().numpy(), r) < 2e-2
+    # the f32 build trains (and applies stochastic depth) on the same bf16-operand kernels; the fp8 build refuses
     m32 = DiTEncoder(cfg).load_numpy(w).to(DEV).train()
-    with pytest.raises(NotImplementedError, match="bf16"):
-        m32(torch.from_numpy(x).to(DEV))
+    with torch.no_grad():
+        hs32 = m32(torch.from_numpy(x).to(DEV)).hidden_states
+    for t in cfg.taps:
+        assert torch.equal(hs32[t], hs[t])
+    m8 = DiTEncoder(cfg, compute_dtype="fp8").load_numpy(w).to(DEV).train()
+    with pytest.raises(NotImplementedError, match="inference only|fp8"):
+        m8(torch.from_numpy(x).to(DEV))
+    # a grid the training forward does not cover is refused, not silently computed without stochastic depth ...
+    x96 = torch.from_numpy(synth.synth_images(2, 96, 96, seed=5, kind="uniform")).to(DEV)
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="eval"):
+        m(x96)
+    # ... and with a drop-path rate of 0 train == eval arithmetic: the inference kernels of the build run
+    m32.config.drop_path_rate = 0.0
+    with torch.no_grad():
+        a = m32(x96).hidden_states[cfg.taps[-1]]
+        b = m32.eval()(x96).hidden_states[cfg.taps[-1]]
+    assert torch.equal(a, b)
+
+
+def test_f32_build_trains_on_the_bf16_kernels_like_the_reference_cpu_branch(monkeypatch):
+    """`DiTEncoder(cfg)` (compute_dtype 'f32') + .train() + loss.backward() (ref trainer.py:171-172,176-178): mixed precision
+    on the bf16 train kernels, every parameter gradient inside the bf16 gate of the float64 oracle; a GradScaler-style scaled
+    loss (ref trainer.py:177-180) gives the same gradients times the scale."""
+    cfg = cfgs.vit_micro()
+    w = synth.synth_weights(cfg, 3)
+    x = synth.synth_images(4, 64, 64, seed=5, kind="uniform")
+    dtaps = upstream(cfg, 4, cfg.tokens(64, 64), 9)
+    m = DiTEncoder(cfg).load_numpy(w).to(DEV).train()
+    m.config.drop_path_rate = 0.0
+    out = m(torch.from_numpy(x).to(DEV))
+    loss = sum((out.hidden_states[t] * torch.from_numpy(d).to(DEV)).sum() for t, d in zip(cfg.taps, dtaps))
+    (loss * 1024.0).backward()
+    _, ref = train_reference(cfg, w, x, dtaps, drop_scales=None)
+    st = m._flat_state
+    for name, p, _, _ in st.named:
+        k = _hf_name(name)
+        assert rel_l2(p.grad.cpu().numpy() / 1024.0, ref[k]) < GRAD_TOL, k
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
+    # eval mode of the same module is still the exact-fp32 path
+    m.eval()
+    with torch.no_grad():
+        h = m(torch.from_numpy(x).to(DEV)).hidden_states[cfg.taps[-1]]
+    ref_taps, _ = train_reference(cfg, w, x, dtaps, drop_scales=None)
+    assert rel_l2(h.cpu().numpy(), ref_taps[-1]) < 2e-5
+
+
+def test_caches_follow_parameter_updates_that_bypass_version_counters():
+    """the fused AdamW updates parameters through raw pointers (no tensor version moves).  After one fused step
+    at 224-style native size, an eval forward at ANOTHER grid must use a position table resampled from the UPDATED
+    embeddings; `.data` writes need FlatState.mark_dirty() to reach the bf16 mirror."""
+    cfg = cfgs.vit_micro()
+    cfg.drop_path_rate = 0.0
+    w = synth.synth_weights(cfg, 3)
+    x = torch.from_numpy(synth.synth_images(4, 64, 64, seed=5, kind="uniform")).to(DEV)
+    x96 = torch.from_numpy(synth.synth_images(2, 96, 96, seed=6, kind="uniform")).to(DEV)
+    m = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(w).to(DEV)
+    with torch.no_grad():
+        before = m.eval()(x96).hidden_states[cfg.taps[-1]].clone()      # fills the resampled-table cache
+    step = training.TrainStep(m.train(), lr=5e-2, weight_decay=0.0, drop_path_rate=0.0, img_size=(64, 64))
+    step.step(x)
+    torch.cuda.synchronize()
+    fresh = DiTEncoder(cfg, compute_dtype="bf16").to(DEV)
+    fresh.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        got = m.eval()(x96).hidden_states[cfg.taps[-1]]
+        want = fresh.eval()(x96).hidden_states[cfg.taps[-1]]
+    assert torch.equal(got, want)
+    assert rel_l2(got.cpu().numpy(), before.cpu().numpy()) > 1e-3          # the step really moved the output
+    # .data writes bypass the version counter: mark_parameters_changed() is the documented hook for every cache
+    m.train()
+    a = m(x).hidden_states[cfg.taps[-1]].detach().clone()                 # autograd path: reads the flat state's bf16 mirror
+    m.encoder.layer[0].intermediate.dense.weight.data.mul_(1.5)
+    m.mark_parameters_changed()
+    b = m(x).hidden_states[cfg.taps[-1]].detach()
+    assert not torch.equal(a, b)
+    fresh = DiTEncoder(cfg, compute_dtype="bf16").to(DEV)
+    fresh.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        assert torch.equal(m.eval()(x96).hidden_states[cfg.taps[-1]], fresh.eval()(x96).hidden_states[cfg.taps[-1]])
 
 
 # ---- reduction-major GEMMs (dgrad / wgrad without transposed copies) --------------------------------------------------------------

@@ -12,7 +12,7 @@ from tests.golden.make_golden_grad import upstream
 from tests.util import rel_l2
 
 
-@pytest.mark.parametrize("name,geom", [("g6_grad_micro.npz", "micro"), ("g7_grad_tiny.npz", "tiny")])
+@pytest.mark.parametrize("name,geom", [("g6_grad_micro.npz", "micro"), ("g7_grad_tiny.npz", "tiny"), ("g8_grad_base.npz", "base")])
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_gradient_oracle_vs_hf_goldens(golden_dir, name, geom, mode):
     g = np.load(os.path.join(golden_dir, name))
