@@ -24,7 +24,8 @@ barrier + synchronize brackets (max over ranks); rank 0 prints ONE JSON line.  E
                  in a second K-step pass with events on the launch stream, against the dense MFMA peak of the dtype;
                  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_traffic.json,
                  labelled with the commit they were collected on) or null
-  cpu_baseline - (N = 1, config 1 only) the same forward on the host cores: the torch-ops restatement in oracle/
+  cpu_baseline - (N = 1, config 1 only) the same forward on the host cores: the torch-ops restatement in oracle/ (value)
+                 and the plain-C OpenMP restatement beside it, best + median of 5, CPU model and core count
 """
 from __future__ import annotations
 
@@ -79,21 +80,55 @@ def free_port() -> int:
 
 
 def launch_children(n: int) -> int:
-    """Parent of an N-rank job.  Touches no GPU API (a process that has initialised the GPU must not spawn-and-wait
-    cheaply here, and must never exec): it only forks the interpreter N times with the rendezvous in the environment."""
+    """Parent of an N-rank job.  Touches no GPU API (a process that has initialised the GPU must never exec, and this one
+    only ever starts fresh interpreters): N children with the rendezvous in their environment.  Every child is polled; the
+    first non-zero exit terminates the others (a rank that died in start-up would otherwise leave rank 0 in the rendezvous
+    until its timeout) and becomes the exit status.  stderr of every rank goes to bench_rank<k>.err under LDIT_BENCH_LOGDIR
+    (default: the system temp dir); rank 0's stdout (the JSON line) is relayed."""
+    import tempfile
     port = free_port()
-    procs = []
+    logdir = os.environ.get("LDIT_BENCH_LOGDIR") or tempfile.mkdtemp(prefix="ldit_bench_")
+    os.makedirs(logdir, exist_ok=True)
+    procs, logs = [], []
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # this pool's driver only supports dmabuf IPC; an operator may override
+        err = open(os.path.join(logdir, f"bench_rank{rank}.err"), "w")
+        logs.append(err)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    worst = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        worst = worst or p.returncode
-    sys.stdout.write(out)
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=err, text=True))
+    import threading
+    out_chunks = []
+    reader = threading.Thread(target=lambda: out_chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    worst, live = 0, set(range(n))
+    while live:
+        for k in sorted(live):
+            rc = procs[k].poll()
+            if rc is None:
+                continue
+            live.discard(k)
+            if rc != 0 and worst == 0:
+                worst = rc
+                sys.stderr.write(f"bench.py: rank {k} exited with status {rc} (log: {logdir}/bench_rank{k}.err); "
+                                 f"stopping the other ranks\n")
+                for j in live:
+                    procs[j].terminate()          # our own fresh children, by handle - never by pattern
+        if live:
+            time.sleep(0.05)
+    reader.join(timeout=5)
+    for err in logs:
+        err.close()
+    if worst != 0:
+        for k in range(n):
+            try:
+                tail = open(os.path.join(logdir, f"bench_rank{k}.err")).read()[-2000:]
+            except OSError:
+                tail = ""
+            if tail.strip():
+                sys.stderr.write(f"---- rank {k} stderr (tail) ----\n{tail}\n")
+    sys.stdout.write("".join(out_chunks))
     sys.stdout.flush()
     return worst
 
@@ -133,24 +168,57 @@ def host_cores() -> int:
     return max(1, n)
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, weights, x_np, sample: int):
-    """Time the torch-ops restatement on the host cores over `sample` images of the same batch."""
+    """The same forward on the host cores, two ways, each 1 warm-up + 5 timed runs, best and median:
+      * the torch-ops restatement (oracle/vit_oracle_torch.py: ATen CPU kernels = what the reference's CPU path executes),
+        over `sample` images of the batch - the reported `value`;
+      * the plain-C restatement with OpenMP (oracle/libvit_oracle_f32.so), over a quarter of that sample (it is the slower
+        of the two; bounded so that the default bench run stays within minutes)."""
+    import statistics
+
     import torch
+    from oracle import oracle as c_oracle
     from oracle.vit_oracle_torch import TorchOracle
     cores = host_cores()
     torch.set_num_threads(cores)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     ora = TorchOracle(cfg, weights)
     xs = torch.from_numpy(x_np[:sample])
     ora.forward(xs[:1])                      # page in / thread pool warm-up (not timed)
-    times = []
-    for _ in range(3):
+    ora.forward(xs)                          # the warm-up run
+    t_torch = []
+    for _ in range(5):
         t0 = time.perf_counter()
         ora.forward(xs)
-        times.append(time.perf_counter() - t0)
-    best = min(times)
+        t_torch.append(time.perf_counter() - t0)
+    n_c = max(1, sample // 4)
+    xc = x_np[:n_c]
+    c_oracle.vit_forward(cfg, weights, xc[:1], f32acc=True)
+    c_oracle.vit_forward(cfg, weights, xc, f32acc=True)
+    t_c = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        c_oracle.vit_forward(cfg, weights, xc, f32acc=True)
+        t_c.append(time.perf_counter() - t0)
+    best, med = min(t_torch), statistics.median(t_torch)
     return {"value": round(sample / best, 3), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "median": round(sample / med, 3), "cpu_model": cpu_model(),
+            "c_openmp": {"value": round(n_c / min(t_c), 3), "median": round(n_c / statistics.median(t_c), 3), "unit": "images/sec",
+                         "cores": cores, "sample": f"{n_c} images, oracle/libvit_oracle_f32.so (plain C + OpenMP, float accumulation), "
+                                                   f"1 warm-up + 5 timed runs"},
             "sample": f"{sample} of the 64 images, ViT-B/16 224x224 fp32, torch CPU ops (oracle/vit_oracle_torch.py), "
-                      f"{cores} threads (cgroup quota), best of 3 runs, {best:.2f} s per run"}
+                      f"{cores} threads (cgroup quota), 1 warm-up + 5 timed runs: value = best ({best:.2f} s per run), "
+                      f"median {med:.2f} s"}
 
 
 def percentiles(ms):
@@ -168,6 +236,9 @@ def run_rank(args) -> None:
 
     if os.environ.get("LDIT_BENCH_DRYRUN") == "1":
         # launcher / rendezvous rehearsal without a GPU (tests/test_dp_gloo.py): join over gloo, reduce, report
+        if os.environ.get("LDIT_BENCH_DRYRUN_FAIL_RANK") == os.environ.get("RANK", "0"):
+            sys.stderr.write("dry run: this rank fails in start-up on request\n")
+            raise SystemExit(3)
         r = dp.init(backend="gloo")
         dp.barrier(r)
         worst = dp.max_over_ranks(r, float(r.rank + 1))
@@ -182,6 +253,8 @@ def run_rank(args) -> None:
         raise SystemExit("bench.py needs a GPU: layoutdit_amd has no CPU path")
     dev = torch.device("cuda", r.local_rank)
     torch.cuda.set_device(dev)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(r.world)))
+    placement = dp.pin_to_gpu_numa(r.local_rank, local_world)           # one process per GPU, on its NUMA node
 
     cfg = cfgs.GEOMETRIES[args.model]()
     weights = synth.synth_weights(cfg, seed=0)
@@ -252,7 +325,8 @@ def run_rank(args) -> None:
                        "parallelism": f"dp{r.world}: batch-sharded replicas, "
                                       + ("bucketed gradient all-reduce (one bucket per layer) overlapped with backward"
                                          if train else "no data-path collective"),
-                       "weights": "synthetic seed 0", "images": "synthetic doc-like pages, seed 1234"},
+                       "weights": "synthetic seed 0", "images": "synthetic doc-like pages, seed 1234",
+                       "rank0_placement": placement},
             "step_ms": percentiles(step_ms),
         }
         mult = 3 if train else 1                       # train step ~ 3x the forward's matmul FLOPs

@@ -277,117 +277,59 @@ int launch_h(const GemmArgsH &a, hipStream_t stream)
     return LDIT_OK;
 }
 
-// ---- skinny kernel: up to 64 rows (the ragged tail peeled off by launch_gemm_bf16) -----------------------------------
-// A 16-row remainder on a 128 x 128 tile is a serial K loop of ~0.4 us per k-tile (24 us at K = 4096) with 8 workgroups
-// on the machine.  Here a workgroup owns 64 rows x 64 columns and its EIGHT waves split K: every wave multiplies the
-// whole 64 x 64 tile over K/8 with fragments loaded straight from global memory (no LDS staging: nothing is reused),
-// the eight partial tiles are summed through LDS in a fixed order, then the usual epilogue runs on 8 elements per thread.
+// ---- tail kernel: up to 64 rows (the ragged tail peeled off by launch_gemm_bf16_ex, or a whole problem that small) ----------
+// Round 3: BIT-IDENTICAL to the tile kernels.  A 16-row remainder (M = 16 x 1025 = 64 x 256 + 16) on the tile kernel costs a
+// whole extra round of the machine; the round-1/2 answer was a split-K "skinny" kernel, whose eight K slices summed in another
+// order than a tile's k-loop, so the rows it served (the LAST image of a batch) depended on the batch layout - the strict
+// permutation test had to be relaxed for them - and it cost 11 - 38 us per call (9.6 % of the ViT-L step).  Here one wave owns
+// one 32 x 32 output tile and walks ALL of K in order, one v_mfma_f32_32x32x16_bf16 per 16-deep step into ONE accumulator with
+// the operands in the tile kernel's lane positions: per output element exactly the tile kernel's sequence of MFMAs, hence
+// its bits.  Fragments come straight from global memory (nothing is reused inside a wave; A is shared through L1 / L2 by
+// the N / 32 waves, W by nobody), sixteen 16-B loads per operand in flight per wave (two register sets of eight steps).
+// The epilogue is the tiles' direct store (store_h), spelled with the same fmas.
 template <int EPI>
-__global__ void __launch_bounds__(512, 2) gemm_bf16_skinny(const GemmArgsH p)
+__global__ void __launch_bounds__(64) gemm_bf16_tail(const GemmArgsH p)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *part = reinterpret_cast<float *>(smem);            // [8 waves][64 rows][64 cols]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c32 = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 64;
-    const int kslice = p.K / 8, k0 = wave * kslice;
-
-    int ra[2], rw[2];
+    constexpr int D = 8;                                  // steps per register set
+    const int lane = threadIdx.x, c32 = lane & 31, h = lane >> 5;
+    const int nct = (p.N + 31) / 32;
+    const int n0 = (blockIdx.x % nct) * 32, m0 = (blockIdx.x / nct) * 32;
+    const int ra = m0 + c32 < p.M ? m0 + c32 : p.M - 1, rw = n0 + c32 < p.N ? n0 + c32 : p.N - 1;
+    const bf16_t *ap = p.A + (size_t)ra * p.lda + 8 * h, *wp = p.W + (size_t)rw * p.K + 8 * h;
+    const int nsteps = p.K / 16;
+    f32x16 acc[1][1];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int m = 32 * t + c32, n = n0 + 32 * t + c32;
-        ra[t] = m < p.M ? m : p.M - 1;
-        rw[t] = n < p.N ? n : p.N - 1;
-    }
-    f32x16 acc[2][2];
+    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.0f;
+    bf16x8 xa0[D], wb0[D], xa1[D], wb1[D];
+    auto ld = [&](bf16x8(&xa)[D], bf16x8(&wb)[D], int s0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-    const bf16_t *ap[2] = {p.A + (size_t)ra[0] * p.lda + k0 + 8 * h, p.A + (size_t)ra[1] * p.lda + k0 + 8 * h};
-    const bf16_t *wp[2] = {p.W + (size_t)rw[0] * p.K + k0 + 8 * h, p.W + (size_t)rw[1] * p.K + k0 + 8 * h};
-    // Every wave streams its K slice straight from global memory; four steps of fragment loads are issued before the
-    // first of their MFMAs so that one memory latency covers four steps (the plain load-then-multiply loop was latency
-    // bound: 24 us for the 16-row tail of fc2 at K = 4096).  A tail of <= 32 rows skips the second row tile.
-    const int nsteps = kslice / 16, ni = p.M > 32 ? 2 : 1;
-    for (int s0 = 0; s0 < nsteps; s0 += 4) {
-        bf16x8 xa[4][2], wb[4][2];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (s0 + u >= nsteps) break;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (t < ni) xa[u][t] = *reinterpret_cast<const bf16x8 *>(ap[t] + 16 * (s0 + u));
-                wb[u][t] = *reinterpret_cast<const bf16x8 *>(wp[t] + 16 * (s0 + u));
-            }
+        for (int u = 0; u < D; ++u) {
+            const int s = s0 + u < nsteps ? s0 + u : nsteps - 1;          // clamped: a step past the end is loaded, never multiplied
+            xa[u] = *reinterpret_cast<const bf16x8 *>(ap + 16 * s);
+            wb[u] = *reinterpret_cast<const bf16x8 *>(wp + 16 * s);
         }
+    };
+    auto mm = [&](const bf16x8(&xa)[D], const bf16x8(&wb)[D], int s0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (s0 + u >= nsteps) break;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (i >= ni) break;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[u][j], xa[u][i], acc[i][j], 0, 0, 0);
-            }
-        }
+        for (int u = 0; u < D; ++u)
+            if (s0 + u < nsteps) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[u], xa[u], acc[0][0], 0, 0, 0);
+    };
+    ld(xa0, wb0, 0);
+    for (int s0 = 0; s0 < nsteps; s0 += 2 * D) {
+        ld(xa1, wb1, s0 + D);
+        mm(xa0, wb0, s0);
+        ld(xa0, wb0, s0 + 2 * D);
+        mm(xa1, wb1, s0 + D);
     }
-    // partial tile of this wave -> LDS: acc[i][j][4g+e] = (row 32i + c32, col 32j + 8g + 4h + e)
-    float *mine = part + wave * 4096;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                *reinterpret_cast<f32x4 *>(mine + (32 * i + c32) * 64 + 32 * j + 8 * g + 4 * h) = v;
-            }
-    __syncthreads();
-    // fixed-order sum of the eight partials; thread t owns row t / 8, columns 8 (t % 8) .. +7
-    const int row = tid >> 3, col = (tid & 7) * 8;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(part + w * 4096 + row * 64 + col);
-        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(part + w * 4096 + row * 64 + col + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { s0[e] += a0[e]; s1[e] += a1[e]; }
-    }
-    if (row >= p.M) return;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int n = n0 + col + e;
-        if (n >= p.N) break;
-        float t = (e < 4 ? s0[e] : s1[e - 4]) + (p.bias ? p.bias[n] : 0.0f);
-        const size_t o = (size_t)row * p.ldy + n;
-        if (EPI == EPI_SCALE_RESID && p.x.Ypre) static_cast<bf16_t *>(p.x.Ypre)[o] = (bf16_t)t;
-        if (EPI == EPI_BIAS_GELU && p.x.Ypre) static_cast<bf16_t *>(p.x.Ypre)[o] = (bf16_t)gelu_grad_lp(t);
-        if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
-        if (EPI == EPI_GELU_BWD) t *= (float)static_cast<const bf16_t *>(p.x.aux)[(size_t)row * p.x.ldaux + n];
-        if (EPI == EPI_SCALE_RESID) {
-            t = p.x.rowscale ? __builtin_fmaf(p.lam[n] * p.x.rowscale[row], t, p.R[o]) : __builtin_fmaf(p.lam[n], t, p.R[o]);
-            static_cast<float *>(p.Y)[o] = t;
-            if (p.Y2) p.Y2[o] = t;
-        } else if (EPI == EPI_F32) {
-            static_cast<float *>(p.Y)[o] = t;
-        } else {
-            static_cast<bf16_t *>(p.Y)[o] = (bf16_t)t;
-        }
-    }
+    if ((n0 + 32 <= p.N) && ((p.ldy & 3) == 0)) store_h<1, 1, EPI, 1>(p, acc, m0, n0, lane);
+    else store_h<1, 1, EPI, 2>(p, acc, m0, n0, lane);
 }
 
 template <int EPI>
-int launch_skinny(const GemmArgsH &a, hipStream_t stream)
+int launch_tail(const GemmArgsH &a, hipStream_t stream)
 {
-    constexpr int lds = 8 * 4096 * 4;
-    auto kern = gemm_bf16_skinny<EPI>;
-    LDIT_DYN_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3((a.N + 63) / 64), dim3(512), lds, stream, a);
+    const unsigned blocks = (unsigned)(((a.N + 31) / 32) * ((a.M + 31) / 32));
+    hipLaunchKernelGGL(gemm_bf16_tail<EPI>, dim3(blocks), dim3(64), 0, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }
@@ -395,7 +337,7 @@ int launch_skinny(const GemmArgsH &a, hipStream_t stream)
 template <int EPI>
 int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
 {
-    if (a.M <= 64 && a.K % 128 == 0 && a.x.splits == 1 && !diag().bf16_tile_env) return launch_skinny<EPI>(a, stream);
+    if (a.M <= 64 && a.x.splits == 1 && !diag().bf16_tile_env) return launch_tail<EPI>(a, stream);
     // Time model fitted to scripts/gemm_bf16_bench.py on ViT-B / ViT-L shapes, M = 3 k .. 25 k (profiles/README.md), in us:
     //   256 x 256, 8 waves (one workgroup per CU):  strict rounds of 256 tiles, each  a[epi] + 19.5e-3 K
     //   128 x 128 (two per CU, they overlap each other's prologue / epilogue):  rounds of 256 tiles, each  r[epi] + 7.6e-3 K,
@@ -453,8 +395,8 @@ static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const flo
 
 // A few rows past a multiple of the 256-row tile (M = 16 x 1025 = 64 x 256 + 16) would cost a whole extra row of
 // workgroups - a full extra round of the machine for N = 1024.  Such a ragged tail is peeled off into a second, tiny
-// launch (split-K skinny kernel); the main part then fills 256 CUs in whole rounds.  The peeled rows are summed in a
-// different k-order than tile rows: the LAST image of such a batch is bit-reproducible only for the same batch layout.
+// launch (gemm_bf16_tail: one wave per 32 x 32 tile over all of K, the tile kernels' own MFMA sequence per output element);
+// the main part then fills 256 CUs in whole rounds.  Peeled rows get the bits a tile would have given them.
 int launch_gemm_bf16_ex(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
                         const float *lam, const float *R, float *Y2, const GemmExtra &x, hipStream_t stream)
 {

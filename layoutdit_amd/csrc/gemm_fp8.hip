@@ -295,110 +295,58 @@ int launch_q(const GemmArgs8 &a, hipStream_t stream)
     return LDIT_OK;
 }
 
-// ---- skinny kernel: up to 64 rows (the ragged tail peeled off by launch_gemm_fp8; same scheme as gemm_bf16_skinny) ---------
-// A workgroup owns 64 rows x 64 columns and its eight waves split K: every wave multiplies the whole tile over K/8 with
-// 8-byte fragments loaded straight from global memory, the partial tiles are summed through LDS in a fixed order, then the
-// epilogue runs on 8 elements per thread.
+// ---- tail kernel: up to 64 rows (the ragged tail peeled off by launch_gemm_fp8, or a whole problem that small) -------------
+// Same scheme as gemm_bf16_tail (gemm_bf16.hip): one wave per 32 x 32 output tile walks ALL of K in order with the tile
+// kernel's own instruction - v_mfma_f32_32x32x64_f8f6f4, a lane's operand = 32 consecutive fp8 of its row at k = 64 s + 32 h -
+// so a peeled row gets the bits a 256 x 256 tile would have given it (the round-2 split-K kernel summed eight K slices of
+// v_mfma_f32_32x32x16_fp8_fp8 products: another order AND another instruction).  Fragments straight from global memory,
+// two register sets of four 64-deep steps.
 template <int EPI>
-__global__ void __launch_bounds__(512, 2) gemm_fp8_skinny(const GemmArgs8 p)
+__global__ void __launch_bounds__(64) gemm_fp8_tail(const GemmArgs8 p)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *part = reinterpret_cast<float *>(smem);            // [8 waves][64 rows][64 cols]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c32 = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 64;
-    const int kslice = p.K / 8, k0 = wave * kslice;
-
-    const unsigned char *ap[2], *wp[2];
+    constexpr int D = 4;
+    const int lane = threadIdx.x, c32 = lane & 31, h = lane >> 5;
+    const int nct = (p.N + 31) / 32;
+    const int n0 = (blockIdx.x % nct) * 32, m0 = (blockIdx.x / nct) * 32;
+    const int ra = m0 + c32 < p.M ? m0 + c32 : p.M - 1, rw = n0 + c32 < p.N ? n0 + c32 : p.N - 1;
+    const unsigned char *ap = p.A + (size_t)ra * p.lda + 32 * h, *wp = p.W + (size_t)rw * p.K + 32 * h;
+    const int nsteps = p.K / 64;
+    f32x16 acc[1][1];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int m = 32 * t + c32, n = n0 + 32 * t + c32;
-        ap[t] = p.A + (size_t)(m < p.M ? m : p.M - 1) * p.lda + k0 + 8 * h;
-        wp[t] = p.W + (size_t)(n < p.N ? n : p.N - 1) * p.K + k0 + 8 * h;
-    }
-    f32x16 acc[2][2];
+    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.0f;
+    i32x8 xa0[D], wb0[D], xa1[D], wb1[D];
+    auto ld = [&](i32x8(&xa)[D], i32x8(&wb)[D], int s0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-    // Every wave streams its K slice straight from global memory; four steps of fragment loads are issued before the
-    // first of their MFMAs so that one memory latency covers four steps (the plain load-then-multiply loop was latency
-    // bound: 24 us for the 16-row tail of fc2 at K = 4096).  A tail of <= 32 rows skips the second row tile.
-    const int nsteps = kslice / 16, ni = p.M > 32 ? 2 : 1;
-    for (int s0 = 0; s0 < nsteps; s0 += 4) {
-        long xa[4][2], wb[4][2];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (s0 + u >= nsteps) break;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (t < ni) xa[u][t] = *reinterpret_cast<const long *>(ap[t] + 16 * (s0 + u));
-                wb[u][t] = *reinterpret_cast<const long *>(wp[t] + 16 * (s0 + u));
-            }
+        for (int u = 0; u < D; ++u) {
+            const int s = s0 + u < nsteps ? s0 + u : nsteps - 1;
+            const i32x4 al = *reinterpret_cast<const i32x4 *>(ap + 64 * s), ah = *reinterpret_cast<const i32x4 *>(ap + 64 * s + 16);
+            const i32x4 wl = *reinterpret_cast<const i32x4 *>(wp + 64 * s), wh = *reinterpret_cast<const i32x4 *>(wp + 64 * s + 16);
+            xa[u] = i32x8{al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+            wb[u] = i32x8{wl[0], wl[1], wl[2], wl[3], wh[0], wh[1], wh[2], wh[3]};
         }
+    };
+    auto mm = [&](const i32x8(&xa)[D], const i32x8(&wb)[D], int s0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (s0 + u >= nsteps) break;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (i >= ni) break;
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(wb[u][j], xa[u][i], acc[i][j], 0, 0, 0);
-            }
-        }
+        for (int u = 0; u < D; ++u)
+            if (s0 + u < nsteps)
+                acc[0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb[u], xa[u], acc[0][0], 0, 0, 0, 0, 0, 0);
+    };
+    ld(xa0, wb0, 0);
+    for (int s0 = 0; s0 < nsteps; s0 += 2 * D) {
+        ld(xa1, wb1, s0 + D);
+        mm(xa0, wb0, s0);
+        ld(xa0, wb0, s0 + 2 * D);
+        mm(xa1, wb1, s0 + D);
     }
-    float *mine = part + wave * 4096;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                *reinterpret_cast<f32x4 *>(mine + (32 * i + c32) * 64 + 32 * j + 8 * g + 4 * h) = v;
-            }
-    __syncthreads();
-    const int row = tid >> 3, col = (tid & 7) * 8;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(part + w * 4096 + row * 64 + col);
-        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(part + w * 4096 + row * 64 + col + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { s0[e] += a0[e]; s1[e] += a1[e]; }
-    }
-    if (row >= p.M) return;
-    const float ab = p.d_act ? p.d_act[0] : p.ab_scale;
-    const float oinv = (EPI == EPI_BIAS_GELU && p.d_out) ? 1.0f / p.d_out[0] : p.out_inv_scale;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int n = n0 + col + e;
-        if (n >= p.N) break;
-        float t = __builtin_fmaf(e < 4 ? s0[e] : s1[e - 4], p.d_wrow ? ab * p.d_wrow[n] : ab, p.bias ? p.bias[n] : 0.0f);
-        const size_t o = (size_t)row * p.ldy + n;
-        if (EPI == EPI_BIAS_GELU) {
-            static_cast<unsigned char *>(p.Y)[o] = (unsigned char)pack_fp8x4(gelu_erf_lp(t) * oinv, 0.f, 0.f, 0.f);
-        } else if (EPI == EPI_SCALE_RESID) {
-            t = __builtin_fmaf(p.lam[n], t, p.R[o]);
-            static_cast<float *>(p.Y)[o] = t;
-            if (p.Y2) p.Y2[o] = t;
-        } else {
-            static_cast<__bf16 *>(p.Y)[o] = (__bf16)t;
-        }
-    }
+    if ((n0 + 32 <= p.N) && ((p.ldy & 3) == 0)) store_q<1, 1, EPI, 1>(p, acc, m0, n0, lane);
+    else store_q<1, 1, EPI, 2>(p, acc, m0, n0, lane);
 }
 
 template <int EPI>
-int launch_qskinny(const GemmArgs8 &a, hipStream_t stream)
+int launch_qtail(const GemmArgs8 &a, hipStream_t stream)
 {
-    constexpr int lds = 8 * 4096 * 4;
-    auto kern = gemm_fp8_skinny<EPI>;
-    LDIT_DYN_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3((a.N + 63) / 64), dim3(512), lds, stream, a);
+    const unsigned blocks = (unsigned)(((a.N + 31) / 32) * ((a.M + 31) / 32));
+    hipLaunchKernelGGL(gemm_fp8_tail<EPI>, dim3(blocks), dim3(64), 0, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }
@@ -408,7 +356,7 @@ int launch_q_tiled(const GemmArgs8 &a, hipStream_t stream)
 {
     // LDIT_GEMM_FP8_K16=1 selects the K = 16 MFMA, LDIT_GEMM_FP8_TILE=0..2 forces a tile (both for experiments / tests)
     const bool k16 = diag().fp8_k16, noskinny = diag().fp8_noskinny;
-    if (a.M <= 64 && !noskinny) return launch_qskinny<EPI>(a, stream);     // peeled tail / tiny batch: split-K
+    if (a.M <= 64 && !noskinny && !k16) return launch_qtail<EPI>(a, stream);     // peeled tail / tiny batch (bit-identical to the K = 64 tiles)
     // Time model fitted to scripts/gemm_fp8_bench.py on ViT-B / ViT-L shapes, M = 3 k .. 25 k (profiles/README.md), in us:
     //   256 x 256 (one workgroup per CU):  strict rounds of 256 tiles, each  a[epi] + 11.3e-3 K
     //   128 x 128 (two per CU, they overlap each other's prologue / epilogue):  rounds of 256 tiles, each  r[epi] + 4.25e-3 K,
@@ -512,8 +460,8 @@ static int launch_gemm_fp8_one(const void *A, int lda, const void *W, const floa
                                int epi, const float *lam, const float *R, float *Y2, float ab_scale, float out_inv_scale,
                                const float *d_act, const float *d_wrow, const float *d_out, hipStream_t stream);
 
-// A ragged tail of up to 64 rows past a multiple of the 256-row tile is peeled off into a second, tiny launch (see
-// launch_gemm_bf16): M = 16 x 1025 = 64 x 256 + 16 would otherwise cost a whole extra round of workgroups.
+// A ragged tail of up to 64 rows past a multiple of the 256-row tile is peeled off into a second, tiny launch (gemm_fp8_tail;
+// see launch_gemm_bf16_ex): M = 16 x 1025 = 64 x 256 + 16 would otherwise cost a whole extra round of workgroups.
 int launch_gemm_fp8(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
                     const float *lam, const float *R, float *Y2, float ab_scale, float out_inv_scale, const float *d_act,
                     const float *d_wrow, const float *d_out, hipStream_t stream)

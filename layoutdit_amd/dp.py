@@ -58,6 +58,48 @@ def init(backend: str | None = None, force_group: bool = False) -> Rank:
     return Rank(rank=rank, world=world, local_rank=local, backend=backend)
 
 
+def _cpulist(text: str) -> set:
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_gpu_numa(local_rank: int, local_world: int) -> str:
+    """Pin this process to the host CPUs of its GPU's NUMA node ("one process per GPU pinned to its NUMA
+    node"): the node is read from sysfs through the device's PCI address; if the platform does not say (node -1, no sysfs,
+    no affinity API) the CPUs this process may use are split evenly over the local ranks instead.  The mask only ever
+    shrinks the inherited one (a cgroup / taskset limit stays in force).  Returns a short description for the bench line."""
+    if not hasattr(os, "sched_getaffinity"):
+        return "unpinned (no affinity API)"
+    allowed = set(os.sched_getaffinity(0))
+    how, want = "", set()
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node >= 0:
+            want = _cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) & allowed
+            how = f"NUMA node {node} of GPU {bdf}"
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        pass
+    if not want and local_world > 1:
+        cpus = sorted(allowed)
+        per = max(1, len(cpus) // local_world)
+        want = set(cpus[local_rank * per: (local_rank + 1) * per]) or allowed
+        how = f"even split of {len(cpus)} allowed CPUs over {local_world} local ranks"
+    if not want or want == allowed:
+        return f"{len(allowed)} CPUs (inherited mask" + (f"; {how})" if how else ")")
+    try:
+        os.sched_setaffinity(0, want)
+    except OSError:
+        return f"{len(allowed)} CPUs (could not narrow the mask)"
+    return f"{len(want)} CPUs: {how}"
+
+
 def barrier(r: Rank) -> None:
     if r.world > 1 or dist.is_initialized():
         if r.backend == "nccl":

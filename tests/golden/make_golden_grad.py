@@ -95,7 +95,15 @@ def stats(a):
     return np.array([np.sqrt((a64 ** 2).sum()), np.abs(a64).max()], dtype=np.float64)
 
 
-def emit(name, cfg, B, size, wseed, xseed, gseed, stride):
+def sample_stride(g, size: int) -> int:
+    """Stride of a gradient's committed sample: `stride`, except that files carrying `small_full` store every tensor of at
+    most that many elements whole (a 768-element bias sampled every 499th element is two numbers - no statistic)."""
+    if "small_full" in g and size <= int(g["small_full"][0]):
+        return 1
+    return int(g["stride"][0])
+
+
+def emit(name, cfg, B, size, wseed, xseed, gseed, stride, small_full=0):
     w = synth.synth_weights(cfg, wseed)
     x = synth.synth_images(B, size, size, seed=xseed, kind="uniform" if size < 224 else "doc")
     N = cfg.tokens(size, size)
@@ -104,6 +112,8 @@ def emit(name, cfg, B, size, wseed, xseed, gseed, stride):
                                   cfg.patch_size, cfg.image_size, B, size], dtype=np.int64),
                seeds=np.array([wseed, xseed, gseed], dtype=np.int64), stride=np.array([stride], dtype=np.int64),
                taps=np.array(cfg.taps, dtype=np.int64), drop_path_rate=np.array([DROP_PATH_RATE]))
+    if small_full:
+        rec["small_full"] = np.array([small_full], dtype=np.int64)
     for mode, train in (("eval", False), ("train", True)):
         # train mode: first torch seed >= 1000 + gseed under which HF drops at least one (layer, branch, sample)
         for rng_seed in range(1000 + gseed, 1100 + gseed):
@@ -115,7 +125,7 @@ def emit(name, cfg, B, size, wseed, xseed, gseed, stride):
         for t, a in zip(cfg.taps, taps):
             rec[f"{mode}_tap{t}_sample"] = a.reshape(-1)[::max(stride, 7)].copy()
         for k, g in grads.items():
-            rec[f"{mode}_grad/{k}"] = g.reshape(-1)[::stride].copy()
+            rec[f"{mode}_grad/{k}"] = g.reshape(-1)[::sample_stride(rec, g.size)].copy()
             rec[f"{mode}_gstat/{k}"] = stats(g)
         if train:
             assert set(np.unique(np.round(scales, 4))) - {0.0, 1.0} != set() or cfg.num_hidden_layers < 2, \
@@ -133,7 +143,7 @@ def main():
         emit("g7_grad_tiny.npz", cfgs.vit_tiny(), 2, 224, wseed=1, xseed=1234, gseed=6, stride=53)
     if only in ("", "g8"):
         # configs[2]'s own geometry (C = 768, 12 heads, F = 3072); the same weight / image seeds as g2_base.npz
-        emit("g8_grad_base.npz", cfgs.vit_base(), 2, 224, wseed=0, xseed=1234, gseed=8, stride=499)
+        emit("g8_grad_base.npz", cfgs.vit_base(), 2, 224, wseed=0, xseed=1234, gseed=8, stride=499, small_full=8192)
 
 
 if __name__ == "__main__":

@@ -88,3 +88,21 @@ def test_bench_launches_itself_at_n_greater_than_one():
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], env=env2, capture_output=True,
                          text=True, timeout=300)
     assert res.returncode == 0 and json.loads(res.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_launcher_stops_all_ranks_when_one_dies_in_start_up(tmp_path):
+    """a rank that dies before the rendezvous must not leave rank 0 waiting for its 10-minute timeout - the
+    parent polls every child, terminates the survivors and returns the failing status, with the rank's stderr kept."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(LDIT_BENCH_DRYRUN="1", LDIT_BENCH_DRYRUN_FAIL_RANK="1", LDIT_BENCH_LOGDIR=str(tmp_path))
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 3
+    assert time.time() - t0 < 120
+    assert "rank 1 exited with status 3" in res.stderr
+    assert "fails in start-up on request" in (tmp_path / "bench_rank1.err").read_text()

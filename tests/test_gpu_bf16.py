@@ -135,8 +135,8 @@ def test_linear_bf16_ragged_tail_is_peeled():
 
 
 @pytest.mark.parametrize("M,N,K", [(16, 1024, 1024), (1, 128, 128), (64, 320, 4096), (37, 200, 256)])
-def test_linear_bf16_skinny(M, N, K):
-    """<= 64 rows: the split-K skinny kernel (eight waves share K, fixed-order LDS reduction)."""
+def test_linear_bf16_tail(M, N, K):
+    """<= 64 rows: gemm_bf16_tail (one wave per 32 x 32 tile, all of K in the tile kernels' order)."""
     x, w, b = _bf16_round(_rand(50, M, K)), _bf16_round(_rand(51, N, K, scale=0.05)), _rand(52, N, scale=0.1)
     xd, wd, bd = (torch.from_numpy(x).to(DEV).to(torch.bfloat16), torch.from_numpy(w).to(DEV).to(torch.bfloat16),
                   torch.from_numpy(b).to(DEV))
@@ -147,6 +147,28 @@ def test_linear_bf16_skinny(M, N, K):
     ops.linear_bf16(xd, wd, bd, epilogue=_lib.EPI_SCALE_RESID, lam=torch.from_numpy(lam).to(DEV), residual=h, out=h)
     ref = (r.astype(np.float64) + lam.astype(np.float64) * oracle.linear(x, w, b).astype(np.float64)).astype(np.float32)
     assert rel_l2(h.cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,rows", [(1040, 1024, 1024, 16), (600, 320, 4096, 64), (528, 200, 192, 37)])
+@pytest.mark.parametrize("tile", ["auto", "2", "3", "4", "5"])
+def test_linear_bf16_tail_rows_have_the_bits_of_tile_rows(M, N, K, rows, tile):
+    """Batch invariance at the kernel level: the last `rows` rows computed ALONE (tail kernel) equal, bit for bit, the same
+    rows inside the big problem - whichever tile height serves them there (128 / 256 / 192 / 320 rows, or the peeled tail) and
+    for every epilogue.  A DP shard boundary or a permutation moves token rows between exactly these two situations."""
+    x, w, b = _bf16_round(_rand(60, M, K)), _bf16_round(_rand(61, N, K, scale=0.05)), _rand(62, N, scale=0.1)
+    xd, wd, bd = (torch.from_numpy(x).to(DEV).to(torch.bfloat16), torch.from_numpy(w).to(DEV).to(torch.bfloat16),
+                  torch.from_numpy(b).to(DEV))
+    lam, r = torch.from_numpy(np.abs(_rand(63, N)) * 0.3 + 0.05).to(DEV), torch.from_numpy(_rand(64, M, N)).to(DEV)
+    xt = xd[M - rows:].contiguous()
+    for epi in (_lib.EPI_BIAS, _lib.EPI_BIAS_GELU, _lib.EPI_SCALE_RESID):
+        kw = dict(lam=lam, residual=r) if epi == _lib.EPI_SCALE_RESID else {}
+        kt = dict(lam=lam, residual=r[M - rows:].contiguous()) if epi == _lib.EPI_SCALE_RESID else {}
+        if tile != "auto":
+            _lib.set_switch("LDIT_GEMM_BF16_TILE", tile)
+        big = ops.linear_bf16(xd, wd, bd, epilogue=epi, **kw)
+        _lib.set_switch("LDIT_GEMM_BF16_TILE", None)
+        small = ops.linear_bf16(xt, wd, bd, epilogue=epi, **kt)
+        assert torch.equal(big[M - rows:], small), (epi, tile)
 
 
 def test_forward_bf16_is_batch_invariant():

@@ -152,8 +152,10 @@ def test_error_behaviour():
     with pytest.raises(RuntimeError, match="no CPU"):
         m(torch.zeros(1, 3, 64, 64))
     m.train()
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 3, 64, 64, device=DEV))
+    out = m(torch.zeros(1, 3, 64, 64, device=DEV))             # round 3: the f32 build trains (bf16 operands, fp32 master weights)
+    assert out.hidden_states[3].requires_grad
+    with pytest.raises(NotImplementedError, match="position table's own grid"):
+        m(torch.zeros(1, 3, 96, 96, device=DEV))               # no backward of the bicubic position resample
     for p in m.parameters():
         p.requires_grad_(False)
     assert m(torch.zeros(1, 3, 64, 64, device=DEV)).hidden_states[3] is not None   # frozen backbone in train mode is fine

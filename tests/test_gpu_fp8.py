@@ -70,6 +70,30 @@ def test_linear_fp8_bias(M, N, K):
     assert max_rel(y, ref) < 1.6e-2        # <= one bf16 ulp of max(|ref|, 1)
 
 
+@pytest.mark.parametrize("M,N,K,rows", [(1040, 1024, 1024, 16), (600, 320, 3072, 64), (528, 200, 256, 37)])
+@pytest.mark.parametrize("tile", ["auto", "0", "2", "3"])
+def test_linear_fp8_tail_rows_have_the_bits_of_tile_rows(M, N, K, rows, tile):
+    """gemm_fp8_tail (<= 64 rows, one wave per 32 x 32 tile over all of K on v_mfma_f32_32x32x64_f8f6f4) gives a row the bits
+    the 256 / 128 / 192-row tiles give it - every epilogue, per-channel weight scales included."""
+    x, w, b = _rand(60, M, K), _rand(61, N, K, scale=0.05), _rand(62, N, scale=0.1)
+    sx, sw = float(np.abs(x).max()) / 448.0, float(np.abs(w).max()) / 448.0
+    xq, _ = _codes(x, sx)
+    wq, _ = _codes(w, sw)
+    xq, wq, bd = xq.to(DEV), wq.to(DEV), torch.from_numpy(b).to(DEV)
+    ws = torch.from_numpy(np.abs(_rand(65, N)) + 0.5).to(DEV)
+    lam, r = torch.from_numpy(_rand(63, N, scale=0.3)).to(DEV), torch.from_numpy(_rand(64, M, N)).to(DEV)
+    xt = xq[M - rows:].contiguous()
+    for epi in (_lib.EPI_BIAS, _lib.EPI_BIAS_GELU, _lib.EPI_SCALE_RESID):
+        kw = dict(lam=lam, residual=r) if epi == _lib.EPI_SCALE_RESID else {}
+        kt = dict(lam=lam, residual=r[M - rows:].contiguous()) if epi == _lib.EPI_SCALE_RESID else {}
+        if tile != "auto":
+            _lib.set_switch("LDIT_GEMM_FP8_TILE", tile)
+        big = ops.linear_fp8(xq, wq, sx * sw, bd, epilogue=epi, out_scale=0.01, w_scales=ws, **kw)
+        _lib.set_switch("LDIT_GEMM_FP8_TILE", None)
+        small = ops.linear_fp8(xt, wq, sx * sw, bd, epilogue=epi, out_scale=0.01, w_scales=ws, **kt)
+        assert torch.equal(big[M - rows:].view(torch.uint8), small.view(torch.uint8)), (epi, tile)
+
+
 @pytest.mark.parametrize("M,N,K", [(394, 320, 128), (4500, 768, 3072)])
 def test_linear_fp8_scale_residual_fp32(M, N, K):
     x, w, b = _rand(4, M, K), _rand(5, N, K, scale=0.2), _rand(6, N)

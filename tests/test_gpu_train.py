@@ -25,7 +25,7 @@ from layoutdit_amd import _lib, config as cfgs, synth, training   # noqa: E402
 from layoutdit_amd.modeling import DiTEncoder              # noqa: E402
 from oracle import oracle                                  # noqa: E402
 from oracle.vit_oracle_torch import train_reference        # noqa: E402
-from tests.golden.make_golden_grad import upstream         # noqa: E402
+from tests.golden.make_golden_grad import sample_stride, upstream         # noqa: E402
 from tests.util import rel_l2                              # noqa: E402
 
 DEV = "cuda:0"
@@ -258,7 +258,7 @@ def test_parameter_gradients_vs_oracle_and_hf_golden(golden_dir, monkeypatch, na
         worst[k.split(".")[-2] + "." + k.split(".")[-1]] = max(worst.get(k.split(".")[-2] + "." + k.split(".")[-1], 0.0), e)
         assert e < GRAD_TOL, (k, e)
         hf = g[f"{mode}_grad/{k}"]                       # HF BeitModel's own gradient, strided sample
-        assert rel_l2(got.reshape(-1)[::stride], hf) < GRAD_TOL, (k, "vs HF golden")
+        assert rel_l2(got.reshape(-1)[::sample_stride(g, got.size)], hf) < GRAD_TOL, (k, "vs HF golden")
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/grad_parity_{geom}_{mode}.txt", "w") as f:
         for k, e in sorted(worst.items(), key=lambda kv: -kv[1]):
@@ -302,7 +302,7 @@ def test_config2_full_size_train_step_vs_hf_golden_and_properties(golden_dir):
     for name, p, off, shape in st.named:
         k = _hf_name(name)
         got = st.grad_view(off, shape).cpu().numpy()
-        e = rel_l2(got.reshape(-1)[::stride], g[f"eval_grad/{k}"])
+        e = rel_l2(got.reshape(-1)[::sample_stride(g, got.size)], g[f"eval_grad/{k}"])
         worst = max(worst, e)
         assert e < GRAD_TOL, (k, e, "bs=64 step vs HF golden of its first two images")
     # -- 2. batch invariance of the training forward
