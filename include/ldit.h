@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LDIT_ABI_VERSION 2
+#define LDIT_ABI_VERSION 3
 #define LDIT_MAX_TAPS 8
 
 enum ldit_status {
@@ -262,6 +262,23 @@ int ldit_fpn_merge_f32(const void *lat, const void *top, void *out, int64_t B, i
                        int64_t top_h, int64_t top_w, ldit_stream stream);
 int ldit_conv3x3_nhwc_f32(const void *x, const void *w, const void *bias, void *y, int64_t B, int64_t H, int64_t W, int64_t Cin,
                           int64_t Cout, const void *zeros, ldit_stream stream);
+
+/* ---- FPN backward (training through `self.fpn(feats)`, ref dit_backbone.py:87-90 under ref trainer.py:169-178).  The MFMA work
+ * reuses entry points above and below (layoutdit_amd/modeling/dit_fpn.py sequences them): dgrad of a 3x3 convolution =
+ * ldit_conv3x3_nhwc_f32 on the flipped / in-out-swapped weight; wgrad of a 3x3 convolution = nine ldit_linear_bf16_tr (wgrad
+ * form) on zero-padded bf16 NHWC copies, one per tap (a tap is a constant row offset of the padded input); laterals =
+ * ldit_linear_f32 / ldit_linear_bf16_tr.  New here:
+ *   ldit_fpn_merge_bwd_f32:  adjoint of ldit_fpn_merge_f32.  d_inner [B, Gh*s, Gw*s, Ch] NHWC ->
+ *                            d_lat [B, 1+Gh*Gw, Ch] (written; CLS row = 0; may be NULL) and d_top [B, top_h, top_w, Ch]
+ *                            (ACCUMULATED into: it already holds the coarser level's own 3x3 dgrad; may be NULL).  Gather form.
+ *   ldit_pad_nhwc_f32_bf16:  dst bf16 [B, H+2, W+2, C] = zero-padded copy of src fp32 [B, H, W, C] (every element written)
+ *   ldit_colsum_f32:         out[n] = sum_m x[m * ldx + n] (bias gradients), two stages in a fixed order;
+ *                            scratch: ldit_colsum_scratch_bytes(M, N) */
+int ldit_fpn_merge_bwd_f32(const void *d_inner, void *d_lat, void *d_top, int64_t B, int64_t Gh, int64_t Gw, int64_t Ch, float scale,
+                           int64_t top_h, int64_t top_w, ldit_stream stream);
+int ldit_pad_nhwc_f32_bf16(const void *src, void *dst, int64_t B, int64_t H, int64_t W, int64_t C, ldit_stream stream);
+size_t ldit_colsum_scratch_bytes(int64_t M, int64_t N);
+int ldit_colsum_f32(const void *x, int64_t M, int64_t N, int64_t ldx, void *out, void *scratch, size_t scratch_bytes, ldit_stream stream);
 
 /* ==== train step (BASELINE.json configs[2]: ViT-B/16 bs=64 bf16 forward + backward + AdamW) =============
  * Replaces, for the encoder, what the reference's loop runs through torch.autograd and torch.optim:

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libldit_hip.so")
 
-LDIT_ABI_VERSION = 2
+LDIT_ABI_VERSION = 3
 LDIT_MAX_TAPS = 8
 DTYPE_F32, DTYPE_BF16, DTYPE_FP8 = 0, 1, 3
 FP8_A_COUNT = 4
@@ -75,6 +75,10 @@ SIGNATURES = {
     "ldit_cast_f32_f16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "ldit_fpn_merge_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _i64, _i64, _vp]),
     "ldit_conv3x3_nhwc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "ldit_fpn_merge_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _i64, _i64, _vp]),
+    "ldit_pad_nhwc_f32_bf16": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "ldit_colsum_scratch_bytes": (_sz, [_i64, _i64]),
+    "ldit_colsum_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     # train step
     "ldit_flat_param_bytes": (_sz, [C.POINTER(LditCfg)]),
     "ldit_flat_param_layout": (C.c_int, [C.POINTER(LditCfg), C.POINTER(_i64), _i32]),

@@ -511,6 +511,29 @@ int ldit_conv3x3_nhwc_f32(const void *x, const void *w, const void *bias, void *
     return launch_gemm(a, EPI_BIAS, A_CONV3, static_cast<hipStream_t>(stream));
 }
 
+int ldit_fpn_merge_bwd_f32(const void *d_inner, void *d_lat, void *d_top, int64_t B, int64_t Gh, int64_t Gw, int64_t Ch, float scale,
+                           int64_t top_h, int64_t top_w, ldit_stream stream)
+{
+    if (B * (Gh * Gw + 1) * Ch >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "fpn_merge_bwd: operand exceeds 2^31 elements");
+    return launch_fpn_merge_bwd(static_cast<const float *>(d_inner), static_cast<float *>(d_lat), static_cast<float *>(d_top), (int)B,
+                                (int)Gh, (int)Gw, (int)Ch, scale, (int)top_h, (int)top_w, static_cast<hipStream_t>(stream));
+}
+
+int ldit_pad_nhwc_f32_bf16(const void *src, void *dst, int64_t B, int64_t H, int64_t W, int64_t C, ldit_stream stream)
+{
+    if (B * (H + 2) * (W + 2) * C >= (1ll << 33)) return fail(LDIT_EUNSUPPORTED, "pad_nhwc: operand too large");
+    return launch_pad_nhwc_bf16(static_cast<const float *>(src), dst, (int)B, (int)H, (int)W, (int)C, static_cast<hipStream_t>(stream));
+}
+
+size_t ldit_colsum_scratch_bytes(int64_t M, int64_t N) { return (M > 0 && N > 0) ? colsum_scratch_bytes(M, N) : 0; }
+
+int ldit_colsum_f32(const void *x, int64_t M, int64_t N, int64_t ldx, void *out, void *scratch, size_t scratch_bytes, ldit_stream stream)
+{
+    if (N >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "colsum: too many columns");
+    return launch_colsum_f32(static_cast<const float *>(x), M, (int)N, ldx, static_cast<float *>(out), static_cast<float *>(scratch),
+                             scratch_bytes, static_cast<hipStream_t>(stream));
+}
+
 int ldit_cast_f16_f32(const void *src, void *dst, int64_t n, ldit_stream stream)
 {
     if (n < 0 || (n && (!src || !dst))) return fail(LDIT_EINVAL, "cast: null operand");

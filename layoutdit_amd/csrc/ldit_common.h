@@ -199,6 +199,12 @@ int launch_preprocess(const void *const *images, bool half_in, const int *height
 int launch_cast_f16(const void *src, void *dst, size_t n, bool widen, hipStream_t stream);
 int launch_fpn_merge(const float *lat, const float *top, float *out, int B, int Gh, int Gw, int Ch, float scale, int top_h,
                      int top_w, hipStream_t stream);
+// FPN backward (fpn_bwd.hip)
+int launch_fpn_merge_bwd(const float *din, float *dlat, float *dtop, int B, int Gh, int Gw, int Ch, float scale, int top_h, int top_w,
+                         hipStream_t stream);
+int launch_pad_nhwc_bf16(const float *src, void *dst, int B, int H, int W, int C, hipStream_t stream);
+size_t colsum_scratch_bytes(int64_t M, int64_t N);
+int launch_colsum_f32(const float *x, int64_t M, int N, int64_t ld, float *out, float *scratch, size_t scratch_bytes, hipStream_t stream);
 int launch_gemm_bf16(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
                      const float *lam, const float *R, float *Y2, hipStream_t stream);
 int launch_gemm_bf16_ex(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,

@@ -336,3 +336,77 @@ def conv3x3_nhwc(x: torch.Tensor, weight_ohwi: torch.Tensor, bias: Optional[torc
     _launch(_device(x, weight_ohwi, bias), lib.ldit_conv3x3_nhwc_f32, _ptr(x), _ptr(weight_ohwi), _ptr(bias), _ptr(y), B, H, W, Cin,
             Cout, _ptr(_zero_page(x.device)))
     return y
+
+
+# ---- FPN backward building blocks (include/ldit.h "FPN backward") ------------------------------------------------------------
+def fpn_merge_bwd(d_inner: torch.Tensor, gh: int, gw: int, scale: float, d_top: Optional[torch.Tensor] = None,
+                  want_lat: bool = True) -> Optional[torch.Tensor]:
+    """Adjoint of :func:`fpn_merge`.  ``d_inner``: [B, gh*s, gw*s, Ch] NHWC.  Returns ``d_lat`` [B, 1+gh*gw, Ch] (CLS row 0)
+    and ACCUMULATES the nearest-upsample adjoint into ``d_top`` [B, th, tw, Ch] (in place) when given."""
+    lib = _lib.load()
+    d_inner = _req(d_inner, "d_inner")
+    B, _, _, Ch = d_inner.shape
+    if d_top is not None:
+        _req(d_top, "d_top")
+    d_lat = torch.empty((B, gh * gw + 1, Ch), device=d_inner.device, dtype=torch.float32) if want_lat else None
+    th, tw = (0, 0) if d_top is None else (d_top.shape[1], d_top.shape[2])
+    _launch(_device(d_inner, d_top), lib.ldit_fpn_merge_bwd_f32, _ptr(d_inner), _ptr(d_lat), _ptr(d_top), B, gh, gw, Ch, float(scale),
+            th, tw)
+    return d_lat
+
+
+def pad_nhwc_bf16(x: torch.Tensor, slack_rows: int = 0) -> torch.Tensor:
+    """bf16 zero-padded copy of an fp32 NHWC map as a 2-D operand: returns ``[slack + B*(H+2)*(W+2) + slack, C]`` bf16 whose
+    middle rows are the padded pixels in (b, y, x) order and whose ``slack_rows`` leading / trailing rows are zero (room for
+    the constant row offsets of the 3x3 taps, see ``layoutdit_amd/csrc/fpn_bwd.hip``)."""
+    lib = _lib.load()
+    x = _req(x, "x")
+    B, H, W, Cc = x.shape
+    rows = B * (H + 2) * (W + 2)
+    buf = torch.zeros((rows + 2 * slack_rows, Cc), device=x.device, dtype=torch.bfloat16)
+    _launch(_device(x), lib.ldit_pad_nhwc_f32_bf16, _ptr(x), buf[slack_rows:].data_ptr(), B, H, W, Cc)
+    return buf
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """``x.sum(0)`` of a contiguous fp32 [M, N] matrix (two stages, fixed order)."""
+    lib = _lib.load()
+    x = _req(x, "x")
+    M, N = x.shape
+    out = torch.empty(N, device=x.device, dtype=torch.float32)
+    need = ((M + 511) // 512) * N * 4                  # = ldit_colsum_scratch_bytes(M, N): one partial row per 512 rows
+    scratch = torch.empty(max(need, 16), device=x.device, dtype=torch.uint8)
+    _launch(_device(x), lib.ldit_colsum_f32, _ptr(x), M, N, N, _ptr(out), _ptr(scratch), need)
+    return out
+
+
+def _splits_for(K: int, tiles: int) -> int:
+    """K-splits of a wgrad GEMM: enough workgroups for the machine (~512 / output tiles), every split non-empty."""
+    nk = (K + 63) // 64
+    s = max(1, min(nk, 512 // max(tiles, 1)))
+    while s > 1 and ((nk + s - 1) // s) * (s - 1) >= nk:
+        s -= 1
+    return s
+
+
+def wgrad_bf16(a: torch.Tensor, w: torch.Tensor, K: int, w_row_offset: int = 0) -> torch.Tensor:
+    """``a[:K].T @ w[w_row_offset : w_row_offset + K]`` with both operands reduction-major bf16 (gemm_bf16_tr.hip, wgrad form):
+    ``a`` [>= K, M], ``w`` [>= w_row_offset + K, N] contiguous.  fp32 [M, N]; K is split over workgroups into slabs that are
+    summed in a fixed order."""
+    lib = _lib.load()
+    for t, n in ((a, "a"), (w, "w")):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous() or t.dim() != 2:
+            raise ValueError(f"{n}: expected a contiguous 2-D bfloat16 GPU tensor")
+    if a.shape[0] < K or w_row_offset < 0 or w.shape[0] < w_row_offset + K:
+        raise ValueError("wgrad_bf16: K rows are not available in both operands")
+    M, N = a.shape[1], w.shape[1]
+    dev = _device(a, w)
+    splits = _splits_for(K, ((M + 127) // 128) * ((N + 127) // 128))
+    slabs = torch.empty((splits, M, N), device=dev, dtype=torch.float32)
+    _launch(_device(a, w), lib.ldit_linear_bf16_tr, a.data_ptr(), M, 1, w[w_row_offset:].data_ptr(), N, slabs.data_ptr(), N, M, N, K,
+            _lib.EPI_F32, None, splits, _zero_page(dev).data_ptr())
+    if splits == 1:
+        return slabs[0]
+    out = torch.empty((M, N), device=dev, dtype=torch.float32)
+    _launch(_device(slabs), lib.ldit_reduce_slabs_f32, slabs.data_ptr(), out.data_ptr(), M * N, splits)
+    return out

@@ -33,9 +33,9 @@ def backbone_maps(taps: Sequence[np.ndarray], gh: int, gw: int, scales=(4.0, 2.0
     return maps
 
 
-def fpn_forward(maps: Sequence[torch.Tensor], weights: Dict[str, np.ndarray]) -> "OrderedDict[str, np.ndarray]":
-    """``weights``: torchvision-named arrays ``inner_blocks.{i}.0.weight/bias``, ``layer_blocks.{i}.0.weight/bias``."""
-    w = {k: torch.from_numpy(np.ascontiguousarray(v)).double() for k, v in weights.items()}
+def fpn_forward_t(maps: Sequence[torch.Tensor], w: Dict[str, torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
+    """The stage on torch tensors (float64), graph kept: autograd of this function is the gradient oracle of the FPN backward
+    (tests/test_gpu_fpn.py)."""
     n = len(maps)
     inner = lambda i, t: F.conv2d(t, w[f"inner_blocks.{i}.0.weight"], w[f"inner_blocks.{i}.0.bias"])            # noqa: E731
     layer = lambda i, t: F.conv2d(t, w[f"layer_blocks.{i}.0.weight"], w[f"layer_blocks.{i}.0.bias"], padding=1)  # noqa: E731
@@ -48,4 +48,21 @@ def fpn_forward(maps: Sequence[torch.Tensor], weights: Dict[str, np.ndarray]) ->
         results.insert(0, layer(idx, last_inner))
     results.append(F.max_pool2d(results[-1], kernel_size=1, stride=2, padding=0))
     names = [f"p{i + 2}" for i in range(n)] + ["pool"]
-    return OrderedDict((k, r.to(torch.float32).numpy()) for k, r in zip(names, results))
+    return OrderedDict(zip(names, results))
+
+
+def backbone_maps_t(taps: Sequence[torch.Tensor], gh: int, gw: int, scales=(4.0, 2.0, 1.0, 0.5)) -> List[torch.Tensor]:
+    """ref dit_backbone.py:50-61 on float64 tensors [B, 1+P, C], graph kept."""
+    maps = []
+    for t, s in zip(taps, scales):
+        t = t[:, 1:, :].permute(0, 2, 1).reshape(t.shape[0], t.shape[2], gh, gw)
+        if s != 1.0:
+            t = F.interpolate(t, scale_factor=s, mode="bilinear", align_corners=False)
+        maps.append(t)
+    return maps
+
+
+def fpn_forward(maps: Sequence[torch.Tensor], weights: Dict[str, np.ndarray]) -> "OrderedDict[str, np.ndarray]":
+    """``weights``: torchvision-named arrays ``inner_blocks.{i}.0.weight/bias``, ``layer_blocks.{i}.0.weight/bias``."""
+    w = {k: torch.from_numpy(np.ascontiguousarray(v)).double() for k, v in weights.items()}
+    return OrderedDict((k, r.to(torch.float32).numpy()) for k, r in fpn_forward_t(maps, w).items())
