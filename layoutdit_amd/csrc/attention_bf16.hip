@@ -50,6 +50,18 @@ __device__ __forceinline__ void glds16a(const void *gsrc, char *lds_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+// LDS-DMA piece with a wave-uniform 64-bit base in SGPRs and a per-lane 32-bit BYTE offset: `global_load_lds_dwordx4 voff, s[base]`
+// (the builtin only takes a per-lane 64-bit pointer: two VALU adds per piece and a live VGPR pair).  M0 (the LDS destination)
+// is compiler-reserved: saved and restored inside the statement (cdna guide 5.7).
+__device__ __forceinline__ void glds16_sbase(const void *ubase, unsigned voff_bytes, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_bytes), "s"(ubase), "s"(lds_dst)
+                 : "memory");
+}
+
 // OUT_FP8: O is written as fp8 e4m3 codes of o / *qscale (operand of the fp8 o_proj GEMM), ldo in elements.
 template <int KT, int NW, bool OUT_FP8>
 __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const bf16_t *__restrict__ Q, const bf16_t *__restrict__ K,
@@ -92,8 +104,30 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
     const int kkey = lane >> 3, vkey = 4 * (lane >> 5) + ((lane & 15) >> 2);
     const int vd = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
     const bf16_t *Kh = K + tok0 * ldk + head * 64, *Vh = V + tok0 * ldv + head * 64;
+    // Per-lane source offsets inside a chunk are constants of the kernel; the chunk's base address is wave-uniform and advances
+    // in scalar registers, so issuing a chunk costs no vector address arithmetic (round 2 recomputed the clamp, the row
+    // product and a 64-bit add per piece: ~30 VALU instructions per chunk on a kernel that is VALU-issue bound).  Only a chunk
+    // that reaches past key N-1 (the short last one) takes the clamped path (rows past N = duplicates of the last key).
+    unsigned koff[PPW], voff[PPW];                      // element offsets
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) {
+        const int piece = wave + NW * u, krow = 8 * piece + kkey;
+        koff[u] = (unsigned)krow * (unsigned)ldk + 8u * ((lane & 7) ^ ((krow >> 1) & 7));     // (x2 = bytes at the use)
+        voff[u] = (unsigned)(8 * piece + vkey) * (unsigned)ldv + (unsigned)vd;
+    }
     auto issue = [&](int stage, int c0) {
         char *kb = smem + stage * STAGE, *vb = kb + HALF;
+        if (c0 + KC <= N) {                              // wave-uniform
+            const bf16_t *kbase = Kh + (size_t)c0 * ldk, *vbase = Vh + (size_t)c0 * ldv;
+            const unsigned kdst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)kb));
+#pragma unroll
+            for (int u = 0; u < PPW; ++u) {
+                const int piece = wave + NW * u;
+                glds16_sbase(kbase, 2u * koff[u], kdst + piece * 1024);
+                glds16_sbase(vbase, 2u * voff[u], kdst + HALF + piece * 1024);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < PPW; ++u) {
             const int piece = wave + NW * u;
