@@ -279,6 +279,9 @@ int ldit_fpn_merge_bwd_f32(const void *d_inner, void *d_lat, void *d_top, int64_
 int ldit_pad_nhwc_f32_bf16(const void *src, void *dst, int64_t B, int64_t H, int64_t W, int64_t C, ldit_stream stream);
 size_t ldit_colsum_scratch_bytes(int64_t M, int64_t N);
 int ldit_colsum_f32(const void *x, int64_t M, int64_t N, int64_t ldx, void *out, void *scratch, size_t scratch_bytes, ldit_stream stream);
+/* out[n] = max_m |x[m * ldx + n]|: per-channel activation ranges for the fp8 build's calibration (the SmoothQuant-style fold of
+ * DiTEncoder.calibrate_fp8: per-channel factors move LayerNorm-output outliers into the next GEMM's weight columns). Same scratch. */
+int ldit_colamax_f32(const void *x, int64_t M, int64_t N, int64_t ldx, void *out, void *scratch, size_t scratch_bytes, ldit_stream stream);
 
 /* ==== train step (BASELINE.json configs[2]: ViT-B/16 bs=64 bf16 forward + backward + AdamW) =============
  * Replaces, for the encoder, what the reference's loop runs through torch.autograd and torch.optim:

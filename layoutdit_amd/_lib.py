@@ -79,6 +79,7 @@ SIGNATURES = {
     "ldit_pad_nhwc_f32_bf16": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "ldit_colsum_scratch_bytes": (_sz, [_i64, _i64]),
     "ldit_colsum_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "ldit_colamax_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     # train step
     "ldit_flat_param_bytes": (_sz, [C.POINTER(LditCfg)]),
     "ldit_flat_param_layout": (C.c_int, [C.POINTER(LditCfg), C.POINTER(_i64), _i32]),

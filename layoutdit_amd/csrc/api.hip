@@ -531,7 +531,14 @@ int ldit_colsum_f32(const void *x, int64_t M, int64_t N, int64_t ldx, void *out,
 {
     if (N >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "colsum: too many columns");
     return launch_colsum_f32(static_cast<const float *>(x), M, (int)N, ldx, static_cast<float *>(out), static_cast<float *>(scratch),
-                             scratch_bytes, static_cast<hipStream_t>(stream));
+                             scratch_bytes, false, static_cast<hipStream_t>(stream));
+}
+
+int ldit_colamax_f32(const void *x, int64_t M, int64_t N, int64_t ldx, void *out, void *scratch, size_t scratch_bytes, ldit_stream stream)
+{
+    if (N >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "colamax: too many columns");
+    return launch_colsum_f32(static_cast<const float *>(x), M, (int)N, ldx, static_cast<float *>(out), static_cast<float *>(scratch),
+                             scratch_bytes, true, static_cast<hipStream_t>(stream));
 }
 
 int ldit_cast_f16_f32(const void *src, void *dst, int64_t n, ldit_stream stream)

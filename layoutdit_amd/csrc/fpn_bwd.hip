@@ -127,7 +127,11 @@ __global__ void __launch_bounds__(256) pad_nhwc_bf16(const float *__restrict__ s
 
 constexpr int CS_ROWS = 512;
 
+// ABSMAX = false: column sums; true: column maxima of |x| (fp8 calibration: per-channel activation ranges)
+template <bool ABSMAX> __device__ __forceinline__ float cs_op(float acc, float v) { return ABSMAX ? fmaxf(acc, fabsf(v)) : acc + v; }
+
 // stage 1: part[blockIdx.x][n] = sum of rows [blockIdx.x * CS_ROWS, +CS_ROWS) of x[:, n]; a thread owns a column
+template <bool ABSMAX>
 __global__ void __launch_bounds__(256) colsum_stage1(const float *__restrict__ x, float *__restrict__ part, long M, int N, long ld)
 {
     const int n = blockIdx.y * 256 + threadIdx.x;
@@ -136,21 +140,22 @@ __global__ void __launch_bounds__(256) colsum_stage1(const float *__restrict__ x
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     long m = m0;
     for (; m + 3 < m1; m += 4) {             // four rows in flight; the summation order is a fixed function of (M, row block)
-        s0 += x[m * ld + n];
-        s1 += x[(m + 1) * ld + n];
-        s2 += x[(m + 2) * ld + n];
-        s3 += x[(m + 3) * ld + n];
+        s0 = cs_op<ABSMAX>(s0, x[m * ld + n]);
+        s1 = cs_op<ABSMAX>(s1, x[(m + 1) * ld + n]);
+        s2 = cs_op<ABSMAX>(s2, x[(m + 2) * ld + n]);
+        s3 = cs_op<ABSMAX>(s3, x[(m + 3) * ld + n]);
     }
-    for (; m < m1; ++m) s0 += x[m * ld + n];
-    part[(long)blockIdx.x * N + n] = (s0 + s1) + (s2 + s3);
+    for (; m < m1; ++m) s0 = cs_op<ABSMAX>(s0, x[m * ld + n]);
+    part[(long)blockIdx.x * N + n] = ABSMAX ? fmaxf(fmaxf(s0, s1), fmaxf(s2, s3)) : (s0 + s1) + (s2 + s3);
 }
 
+template <bool ABSMAX>
 __global__ void __launch_bounds__(256) colsum_stage2(const float *__restrict__ part, float *__restrict__ out, int P, int N)
 {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[(long)p * N + n];
+    for (int p = 0; p < P; ++p) s = ABSMAX ? fmaxf(s, part[(long)p * N + n]) : s + part[(long)p * N + n];
     out[n] = s;
 }
 
@@ -194,16 +199,22 @@ int launch_pad_nhwc_bf16(const float *src, void *dst, int B, int H, int W, int C
 
 size_t colsum_scratch_bytes(int64_t M, int64_t N) { return (size_t)((M + CS_ROWS - 1) / CS_ROWS) * (size_t)N * sizeof(float); }
 
-int launch_colsum_f32(const float *x, int64_t M, int N, int64_t ld, float *out, float *scratch, size_t scratch_bytes, hipStream_t stream)
+int launch_colsum_f32(const float *x, int64_t M, int N, int64_t ld, float *out, float *scratch, size_t scratch_bytes, bool absmax,
+                      hipStream_t stream)
 {
     if (M <= 0 || N <= 0 || ld < N) return fail(LDIT_EINVAL, "colsum: bad geometry");
     if (!x || !out || !scratch) return fail(LDIT_EINVAL, "colsum: null operand");
     if (scratch_bytes < colsum_scratch_bytes(M, N)) return fail(LDIT_EWORKSPACE, "colsum: scratch %zu bytes < required %zu", scratch_bytes, colsum_scratch_bytes(M, N));
     const long P = (M + CS_ROWS - 1) / CS_ROWS;
     if (P > 65535L * 32768L) return fail(LDIT_EUNSUPPORTED, "colsum: too many rows");
-    hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)P, (unsigned)((N + 255) / 256)), dim3(256), 0, stream, x, scratch, (long)M, N, (long)ld);
-    LDIT_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, scratch, out, (int)P, N);
+    const dim3 g1((unsigned)P, (unsigned)((N + 255) / 256)), g2((unsigned)((N + 255) / 256));
+    if (absmax) {
+        hipLaunchKernelGGL(colsum_stage1<true>, g1, dim3(256), 0, stream, x, scratch, (long)M, N, (long)ld);
+        hipLaunchKernelGGL(colsum_stage2<true>, g2, dim3(256), 0, stream, scratch, out, (int)P, N);
+    } else {
+        hipLaunchKernelGGL(colsum_stage1<false>, g1, dim3(256), 0, stream, x, scratch, (long)M, N, (long)ld);
+        hipLaunchKernelGGL(colsum_stage2<false>, g2, dim3(256), 0, stream, scratch, out, (int)P, N);
+    }
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }

@@ -290,7 +290,7 @@ int launch_h(const GemmArgsH &a, hipStream_t stream)
 template <int EPI>
 __global__ void __launch_bounds__(64) gemm_bf16_tail(const GemmArgsH p)
 {
-    constexpr int D = 8;                                  // steps per register set
+    constexpr int D = 8;                                  // steps per register set (two sets: 32 steps = 64 KB in flight per wave)
     const int lane = threadIdx.x, c32 = lane & 31, h = lane >> 5;
     const int nct = (p.N + 31) / 32;
     const int n0 = (blockIdx.x % nct) * 32, m0 = (blockIdx.x / nct) * 32;

@@ -204,7 +204,8 @@ int launch_fpn_merge_bwd(const float *din, float *dlat, float *dtop, int B, int 
                          hipStream_t stream);
 int launch_pad_nhwc_bf16(const float *src, void *dst, int B, int H, int W, int C, hipStream_t stream);
 size_t colsum_scratch_bytes(int64_t M, int64_t N);
-int launch_colsum_f32(const float *x, int64_t M, int N, int64_t ld, float *out, float *scratch, size_t scratch_bytes, hipStream_t stream);
+int launch_colsum_f32(const float *x, int64_t M, int N, int64_t ld, float *out, float *scratch, size_t scratch_bytes, bool absmax,
+                      hipStream_t stream);
 int launch_gemm_bf16(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
                      const float *lam, const float *R, float *Y2, hipStream_t stream);
 int launch_gemm_bf16_ex(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,

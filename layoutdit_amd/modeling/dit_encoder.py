@@ -110,6 +110,10 @@ class DiTEncoder(nn.Module):
         # fp8 activation scales [L, 4] (order: enum ldit_fp8_act); zeros = not calibrated.  Not part of state_dict():
         # the checkpoint stays key-compatible with BeitModel.
         self.register_buffer("fp8_act_scales", torch.zeros(cfg.num_hidden_layers, _lib.FP8_A_COUNT), persistent=False)
+        # fp8: per-channel smoothing factors of the two LayerNorm outputs of every layer ([L, 2, C]; ones = off).  The fold is a
+        # pack-time transform (SmoothQuant): LN gamma / beta are divided by s, the matching input columns of the next GEMM's
+        # weight multiplied by s - the product is unchanged, the fp8 operands are flatter (see calibrate_fp8).
+        self.register_buffer("fp8_smooth", torch.ones(cfg.num_hidden_layers, 2, Cc), persistent=False)
         self._packed: Optional[torch.Tensor] = None
         self._packed_key = None
         self._workspace: Optional[torch.Tensor] = None
@@ -184,7 +188,7 @@ class DiTEncoder(nn.Module):
     def _pack(self, lcfg: _lib.LditCfg, pos: torch.Tensor, device: torch.device) -> torch.Tensor:
         params = [p for p in self.parameters()]
         key = (str(device), lcfg.img_h, lcfg.img_w, lcfg.dtype, pos.data_ptr(),
-               tuple((p.data_ptr(), p._version) for p in params), self.fp8_act_scales._version)
+               tuple((p.data_ptr(), p._version) for p in params), self.fp8_act_scales._version, self.fp8_smooth._version)
         if self._packed is not None and self._packed_key == key:
             return self._packed
         lib = _lib.load()
@@ -206,16 +210,24 @@ class DiTEncoder(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
+        smooth = lcfg.dtype == _lib.DTYPE_FP8 and bool((self.fp8_smooth != 1.0).any())
         for i, blk in enumerate(self.encoder.layer):
             a = blk.attention.attention
             lw = layers[i]
-            lw.ln1_w, lw.ln1_b = ptr(blk.layernorm_before.weight), ptr(blk.layernorm_before.bias)
-            lw.wq, lw.bq, lw.wk = ptr(a.query.weight), ptr(a.query.bias), ptr(a.key.weight)
-            lw.wv, lw.bv = ptr(a.value.weight), ptr(a.value.bias)
+            ln1_w, ln1_b, wq, wk, wv = blk.layernorm_before.weight, blk.layernorm_before.bias, a.query.weight, a.key.weight, a.value.weight
+            ln2_w, ln2_b, w1 = blk.layernorm_after.weight, blk.layernorm_after.bias, blk.intermediate.dense.weight
+            if smooth:
+                # pack-time fold on temporaries (parameter-sized host-side plumbing; the parameters themselves are untouched)
+                s1, s2 = self.fp8_smooth[i, 0].to(device), self.fp8_smooth[i, 1].to(device)
+                ln1_w, ln1_b, ln2_w, ln2_b = ln1_w.detach() / s1, ln1_b.detach() / s1, ln2_w.detach() / s2, ln2_b.detach() / s2
+                wq, wk, wv, w1 = wq.detach() * s1, wk.detach() * s1, wv.detach() * s1, w1.detach() * s2
+            lw.ln1_w, lw.ln1_b = ptr(ln1_w), ptr(ln1_b)
+            lw.wq, lw.bq, lw.wk = ptr(wq), ptr(a.query.bias), ptr(wk)
+            lw.wv, lw.bv = ptr(wv), ptr(a.value.bias)
             lw.wo, lw.bo = ptr(blk.attention.output.dense.weight), ptr(blk.attention.output.dense.bias)
             lw.lam1 = ptr(blk.lambda_1)
-            lw.ln2_w, lw.ln2_b = ptr(blk.layernorm_after.weight), ptr(blk.layernorm_after.bias)
-            lw.w1, lw.b1 = ptr(blk.intermediate.dense.weight), ptr(blk.intermediate.dense.bias)
+            lw.ln2_w, lw.ln2_b = ptr(ln2_w), ptr(ln2_b)
+            lw.w1, lw.b1 = ptr(w1), ptr(blk.intermediate.dense.bias)
             lw.w2, lw.b2 = ptr(blk.output.dense.weight), ptr(blk.output.dense.bias)
             lw.lam2 = ptr(blk.lambda_2)
         proj = self.embeddings.patch_embeddings.projection
@@ -235,10 +247,17 @@ class DiTEncoder(nn.Module):
         return packed
 
     @torch.no_grad()
-    def calibrate_fp8(self, pixel_values: torch.Tensor, margin: float = 1.0) -> torch.Tensor:
+    def calibrate_fp8(self, pixel_values: torch.Tensor, margin: float = 1.0, smooth_alpha: float = 0.5) -> torch.Tensor:
         """Measure the four per-layer activation ranges of the fp8 build on a sample batch and store
         ``scale = margin * amax / 448`` in ``fp8_act_scales``.  Host-side sequencing of the library's own fp32 kernels
-        (``layoutdit_amd.ops``), layer by layer, so the statistics are those of the exact path."""
+        (``layoutdit_amd.ops``), layer by layer, so the statistics are those of the exact path.
+
+        ``smooth_alpha > 0`` (default 0.5) also measures the per-CHANNEL range of the two LayerNorm outputs and stores the
+        SmoothQuant factors ``s_c = amax_c(y)^alpha / amax_c(|W[:, c]|)^(1 - alpha)`` (normalised to geometric mean 1) in
+        ``fp8_smooth``: pretrained BEiT / DiT checkpoints carry a few LayerNorm channels tens of times larger than the rest,
+        which a per-tensor fp8 scale would pay for with the resolution of all others.  Dividing those channels by ``s_c`` in
+        the LayerNorm's affine and multiplying the next GEMM's input columns by ``s_c`` leaves ``y W^T`` unchanged; the
+        weight rows are re-quantised per output channel at pack time as always.  ``smooth_alpha = 0`` turns the fold off."""
         from .. import ops
         cfg = self.config
         if not pixel_values.is_cuda:
@@ -253,7 +272,17 @@ class DiTEncoder(nn.Module):
         T = h.shape[1]
         h = h.reshape(B * T, Cc)
         amax = []
-        for blk in self.encoder.layer:
+        smooth = torch.ones_like(self.fp8_smooth)
+
+        def factors(y2d: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+            """per-channel s and the smoothed activation's per-tensor amax"""
+            ya = ops.colamax(y2d).clamp_min(1e-12)                                  # [C] range of each LayerNorm channel
+            wa = ops.colamax(w).clamp_min(1e-12)                                    # [C] range of the weight's input column
+            s_ = ya.pow(smooth_alpha) / wa.pow(1.0 - smooth_alpha)
+            s_ = s_ / torch.exp(torch.log(s_).mean())                               # geometric mean 1: keeps the overall scale
+            return s_, (ya / s_).amax().reshape(1)
+
+        for li, blk in enumerate(self.encoder.layer):
             a = blk.attention.attention
             y = ops.layernorm(h, blk.layernorm_before.weight.detach(), blk.layernorm_before.bias.detach(), cfg.layer_norm_eps)
             wqkv = torch.cat([a.query.weight, a.key.weight, a.value.weight]).detach().contiguous()
@@ -267,9 +296,15 @@ class DiTEncoder(nn.Module):
                            epilogue=_lib.EPI_BIAS_GELU)
             h = ops.linear(g, blk.output.dense.weight.detach(), blk.output.dense.bias.detach(),
                            epilogue=_lib.EPI_SCALE_RESID, lam=blk.lambda_2.detach(), residual=h, out=h)
-            amax.append(torch.cat([ops.amax(y), ops.amax(o), ops.amax(y2), ops.amax(g)]))
+            if smooth_alpha > 0.0:
+                smooth[li, 0], ay = factors(y, wqkv)
+                smooth[li, 1], ay2 = factors(y2, blk.intermediate.dense.weight.detach().contiguous())
+            else:
+                ay, ay2 = ops.amax(y), ops.amax(y2)
+            amax.append(torch.cat([ay, ops.amax(o), ay2, ops.amax(g)]))
         scales = torch.stack(amax).clamp_min(1e-20) * (float(margin) / ops.FP8_MAX)
         self.fp8_act_scales.copy_(scales)
+        self.fp8_smooth.copy_(smooth)
         return self.fp8_act_scales
 
     def _scratch(self, lcfg: _lib.LditCfg, batch: int, device: torch.device) -> torch.Tensor:

@@ -380,6 +380,18 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def colamax(x: torch.Tensor) -> torch.Tensor:
+    """``x.abs().amax(0)`` of a contiguous fp32 [M, N] matrix (per-channel activation ranges, fp8 calibration)."""
+    lib = _lib.load()
+    x = _req(x, "x")
+    M, N = x.shape
+    out = torch.empty(N, device=x.device, dtype=torch.float32)
+    need = ((M + 511) // 512) * N * 4
+    scratch = torch.empty(max(need, 16), device=x.device, dtype=torch.uint8)
+    _launch(_device(x), lib.ldit_colamax_f32, _ptr(x), M, N, N, _ptr(out), _ptr(scratch), need)
+    return out
+
+
 def _splits_for(K: int, tiles: int) -> int:
     """K-splits of a wgrad GEMM: enough workgroups for the machine (~512 / output tiles), every split non-empty."""
     nk = (K + 63) // 64
