@@ -22,7 +22,7 @@ barrier + synchronize brackets (max over ranks); rank 0 prints ONE JSON line.  E
                  same timed region
   roofline     - the dominant kernel family (the MFMA GEMMs): algorithmic FLOPs / HIP-event time per launch, measured live
                  in a second K-step pass with events on the launch stream, against the dense MFMA peak of the dtype;
-                 `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_traffic.json,
+                 `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_traffic.json,
                  labelled with the commit they were collected on) or null
   cpu_baseline - (N = 1, config 1 only) the same forward on the host cores: the torch-ops restatement in oracle/ (value)
                  and the plain-C OpenMP restatement beside it, best + median of 5, CPU model and core count
@@ -146,10 +146,10 @@ def pmc_traffic(args):
     process), with the commit they were measured on.  Only for the exact workload they were collected on; else null."""
     key = f"{args.mode}:{args.model}:{args.size}:{args.batch}:{args.dtype}"
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
             rec = json.load(f).get(key)
         if rec:
-            return round(rec["gemm_hbm_bytes_per_launch"]), f"profiles/r02_traffic.json[{key}] profiled@{rec['commit']}"
+            return round(rec["gemm_hbm_bytes_per_launch"]), f"profiles/r03_traffic.json[{key}] profiled@{rec['commit']}"
     except (OSError, KeyError, ValueError):
         pass
     return None, None
