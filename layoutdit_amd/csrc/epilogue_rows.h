@@ -84,7 +84,7 @@ __device__ __forceinline__ void store_rows_via_lds(const f32x16 (&acc)[TM][TN], 
                         *reinterpret_cast<epi_bf16x4 *>(static_cast<__bf16 *>(x.Ypre) + o) = pre;
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf_lp(v[e]);
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_lp(v[e]);
                     }
                 }
                 if (EPI == EPI_GELU_BWD) {

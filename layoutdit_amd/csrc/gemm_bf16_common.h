@@ -82,16 +82,20 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bias[g][e];
+                bool gelu_done = false;
                 if ((EPI == EPI_BIAS_GELU || EPI == EPI_SCALE_RESID) && p.x.Ypre) {
-                    // saved for the backward: the pre-LayerScale value, or the GELU derivative at the pre-activation
+                    // saved for the backward: the pre-LayerScale value, or the GELU derivative at the pre-activation (train forward:
+                    // the erf form and ITS derivative from one set of sub-expressions, exactly as the slab epilogue computes them)
                     f32x4 sv = v;
                     if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float ge, gr;
                             gelu_and_grad_lp(v[e], ge, gr);
+                            v[e] = ge;
                             sv[e] = gr;
                         }
+                        gelu_done = true;
                     }
                     bf16_t *yp = static_cast<bf16_t *>(p.x.Ypre);
                     if (MODE != 2) {
@@ -111,7 +115,7 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float t = v[e];
-                    if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
+                    if (EPI == EPI_BIAS_GELU && !gelu_done) t = gelu_lp(t);
                     if (EPI == EPI_SCALE_RESID) t = p.x.rowscale ? __builtin_fmaf(lam[g][e] * rs, t, res[g][e]) : __builtin_fmaf(lam[g][e], t, res[g][e]);
                     v[e] = t;
                 }

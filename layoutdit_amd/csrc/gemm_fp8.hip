@@ -89,7 +89,7 @@ __device__ __forceinline__ void store_q(const GemmArgs8 &p, const f32x16 (&acc)[
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float t = __builtin_fmaf(acc[i][j][4 * g + e], abq[g][e], bias[g][e]);
-                    if (EPI == EPI_BIAS_GELU) t = gelu_erf_lp(t);
+                    if (EPI == EPI_BIAS_GELU) t = gelu_lp(t);
                     if (EPI == EPI_SCALE_RESID) t = __builtin_fmaf(lam[g][e], t, res[g][e]);
                     v[e] = t;
                 }

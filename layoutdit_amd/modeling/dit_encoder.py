@@ -247,17 +247,20 @@ class DiTEncoder(nn.Module):
         return packed
 
     @torch.no_grad()
-    def calibrate_fp8(self, pixel_values: torch.Tensor, margin: float = 1.0, smooth_alpha: float = 0.5) -> torch.Tensor:
+    def calibrate_fp8(self, pixel_values: torch.Tensor, margin: float = 1.0, smooth_alpha: float = 0.0) -> torch.Tensor:
         """Measure the four per-layer activation ranges of the fp8 build on a sample batch and store
         ``scale = margin * amax / 448`` in ``fp8_act_scales``.  Host-side sequencing of the library's own fp32 kernels
         (``layoutdit_amd.ops``), layer by layer, so the statistics are those of the exact path.
 
-        ``smooth_alpha > 0`` (default 0.5) also measures the per-CHANNEL range of the two LayerNorm outputs and stores the
+        ``smooth_alpha > 0`` (0.5 is SmoothQuant's usual value; default 0 = off) also measures the per-CHANNEL range of the two LayerNorm outputs and stores the
         SmoothQuant factors ``s_c = amax_c(y)^alpha / amax_c(|W[:, c]|)^(1 - alpha)`` (normalised to geometric mean 1) in
         ``fp8_smooth``: pretrained BEiT / DiT checkpoints carry a few LayerNorm channels tens of times larger than the rest,
         which a per-tensor fp8 scale would pay for with the resolution of all others.  Dividing those channels by ``s_c`` in
         the LayerNorm's affine and multiplying the next GEMM's input columns by ``s_c`` leaves ``y W^T`` unchanged; the
-        weight rows are re-quantised per output channel at pack time as always.  ``smooth_alpha = 0`` turns the fold off."""
+        weight rows are re-quantised per output channel at pack time as always.  Off by default: on the synthetic outlier stress
+        of tests/test_gpu_lowp_pinning.py it moves the error by -8 ... +1 % only (e4m3's exponent already absorbs a 60x channel;
+        the stress loses its accuracy in the saturated attention logits) - it is there for checkpoints whose LayerNorm
+        outliers exceed what e4m3's range covers."""
         from .. import ops
         cfg = self.config
         if not pixel_values.is_cuda:

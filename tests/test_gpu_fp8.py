@@ -117,7 +117,14 @@ def test_linear_fp8_gelu_requantised(M, N, K):
     sx, sw = float(np.abs(x).max()) / 448.0, float(np.abs(w).max()) / 448.0
     xq, xv = _codes(x, sx)
     wq, wv = _codes(w, sw)
-    ref = oracle.gelu(oracle.linear(xv, wv) * np.float32(sx * sw) + b)
+    pre = oracle.linear(xv, wv) * np.float32(sx * sw) + b
+    exact = oracle.gelu(pre)
+    # the low-precision inference epilogues evaluate the erf-GELU through its logistic form (csrc/ldit_common.h: gelu_lp), a
+    # documented deviation of at most 4.8e-4 - under the fp8 rounding of the result except for a few per cent of the codes
+    # near zero; the CODES are therefore checked against that form, the form against the exact erf-GELU
+    p64 = pre.astype(np.float64)
+    ref = (p64 / (1.0 + np.exp(-(1.5957691216 * p64 + 0.0713548163 * p64 ** 3)))).astype(np.float32)
+    assert float(np.abs(ref - exact).max()) <= 4.8e-4
     so = float(np.abs(ref).max()) / 448.0 * 0.5          # half the range on purpose: the top values must saturate, not NaN
     got = ops.linear_fp8(xq.to(DEV), wq.to(DEV), sx * sw, torch.from_numpy(b).to(DEV), epilogue=_lib.EPI_BIAS_GELU,
                          out_scale=so).cpu()

@@ -32,7 +32,7 @@ def _cos(a, b) -> float:
     return float(a @ b / np.sqrt((a @ a) * (b @ b)))
 
 
-def _build(cfg, w, dtype, size, cal_batch=2, smooth_alpha=0.5):
+def _build(cfg, w, dtype, size, cal_batch=2, smooth_alpha=0.0):
     m = DiTEncoder(cfg, compute_dtype=dtype).load_numpy(w).to(DEV).eval()
     if dtype == "fp8":
         m.calibrate_fp8(torch.from_numpy(synth.synth_images(cal_batch, size, size, seed=CAL_SEED)).to(DEV), smooth_alpha=smooth_alpha)
@@ -162,15 +162,15 @@ def test_outlier_channel_stress(dtype):
         h = hs[t].cpu().numpy()
         rec[str(t)] = {"rel_l2": rel_l2(h, r), "cos": _cos(h, r)}
     if dtype == "fp8":
-        # round 3: the SmoothQuant-style fold (calibrate_fp8(smooth_alpha=0.5), the default) against plain per-tensor
-        # activation scales (smooth_alpha=0, the round-2 build), and the SAME model without outliers: the measured error is
-        # e4m3's 3-bit mantissa noise (its exponent absorbs a 60x channel spread), which the fold can only trim
-        hs0 = _run(_build(cfg, w, dtype, 224, smooth_alpha=0.0), x)
+        # round 3: the SmoothQuant-style fold (calibrate_fp8(smooth_alpha=0.5); off by default) against plain per-tensor
+        # activation scales, and the SAME model without outliers: e4m3's exponent absorbs a 60x channel spread, so the fold
+        # moves the error by a few per cent either way - it must stay a correct transform (inside the gate, near the plain build)
+        hs1 = _run(_build(cfg, w, dtype, 224, smooth_alpha=0.5), x)
         wn = synth.synth_weights(cfg, 4)
         hsn = _run(_build(cfg, wn, dtype, 224), x)
         refn, _ = oracle.vit_forward(cfg, wn, x)
         for t, r, rn in zip(cfg.taps, ref, refn):
-            rec[str(t)]["rel_l2_unsmoothed"] = rel_l2(hs0[t].cpu().numpy(), r)
+            rec[str(t)]["rel_l2_smoothed"] = rel_l2(hs1[t].cpu().numpy(), r)
             rec[str(t)]["rel_l2_no_outliers"] = rel_l2(hsn[t].cpu().numpy(), rn)
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/outlier_stress_{dtype}.json", "w") as f:
@@ -179,4 +179,4 @@ def test_outlier_channel_stress(dtype):
     for t, v in rec.items():
         assert v["rel_l2"] < tol and v["cos"] > cos, (t, v)
         if dtype == "fp8":
-            assert v["rel_l2"] <= v["rel_l2_unsmoothed"], (t, v)                 # the fold never hurts
+            assert v["rel_l2_smoothed"] < min(tol, 1.1 * v["rel_l2"]), (t, v)     # the fold is a correct transform
