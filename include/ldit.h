@@ -293,7 +293,8 @@ int ldit_colamax_f32(const void *x, int64_t M, int64_t N, int64_t ldx, void *out
  * like the fp32 packed block: patch_w, patch_b, cls, pos, then per layer ln1_w, ln1_b, wqkv [3C,C] = [Wq;Wk;Wv],
  * bqkv [3C] = [bq;0;bv] (no key bias, TF:306: that third stays zero and receives a zero gradient), wo, bo, lam1, ln2_w,
  * ln2_b, w1, b1, w2, b2, lam2.  ldit_flat_param_layout writes the 4 + 14 L + 1 float offsets in that order (last = total).
- * Training requires the input grid to be the position table's own grid (no bicubic resampling in the backward). */
+ * The `pos` slot is the position table FOR THE INPUT GRID of cfg ([1 + P, C]); its gradient is with respect to that table (a caller
+ * that resamples embeddings.position_embeddings bicubically chains the resample's own adjoint behind it, as layoutdit_amd.training does). */
 size_t ldit_flat_param_bytes(const ldit_cfg *cfg);
 int ldit_flat_param_layout(const ldit_cfg *cfg, int64_t *offsets, int32_t n);
 
@@ -342,7 +343,8 @@ int ldit_adamw_step(void *params, const void *grads, void *exp_avg, void *exp_av
 /* ldit_attention_bf16 that also writes lse[b][h][q] = log2 sum_k exp2(scale log2(e) q.k)  (fp32 [B, H, N]) */
 int ldit_attention_fwd_lse_bf16(const void *Q, const void *K, const void *V, void *O, void *lse, int64_t B, int64_t N, int64_t H,
                                 int64_t D, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, ldit_stream stream);
-/* dQ, dK, dV (bf16, row stride lddqkv) from Q, K, V (row stride ldqkv), O, dO and the forward's lse.  D == 64, N <= 256. */
+/* dQ, dK, dV (bf16, row stride lddqkv) from Q, K, V (row stride ldqkv), O, dO and the forward's lse.  D == 64.  N <= 256: one
+ * LDS-resident workgroup per (image, head); longer sequences: blocks of 256 rows, one launch per role (dK/dV, dQ). */
 int ldit_attention_bwd_bf16(const void *Q, const void *K, const void *V, const void *O, const void *dO, const void *lse, void *dQ,
                             void *dK, void *dV, int64_t B, int64_t N, int64_t H, int64_t D, int64_t ldqkv, int64_t ldo, int64_t lddo,
                             int64_t lddqkv, float scale, ldit_stream stream);

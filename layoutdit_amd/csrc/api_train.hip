@@ -114,8 +114,6 @@ int train_geometry(const ldit_cfg *cfg, Geo &g)
 {
     LDIT_TRY(geometry(cfg, g));
     if (cfg->dtype != LDIT_BF16) return fail(LDIT_EUNSUPPORTED, "train step: only the bf16 build (cfg.dtype = LDIT_BF16) is implemented");
-    if (g.T > 256) return fail(LDIT_EUNSUPPORTED, "train step: %d tokens per image; the attention backward handles at most 256 "
-                                                  "(the detector trains at 224 x 224 = 197 tokens)", g.T);
     return LDIT_OK;
 }
 

@@ -25,6 +25,18 @@ from ..config import DiTConfig
 from .keys import to_v4
 
 
+def resample_position_table(pe: torch.Tensor, g0: int, gh: int, gw: int) -> torch.Tensor:
+    """``[1, 1 + g0*g0, C]`` position table -> ``[1 + gh*gw, C]`` for another grid: BEiT's ``interpolate_pos_encoding``
+    (TF:models/beit/modeling_beit.py:113-151; bicubic, align_corners=False, CLS row kept).  Plain torch ops on a
+    parameter-sized tensor: host-side plumbing done once per grid, and differentiable - the training path chains its
+    adjoint behind the library's gradient of the resampled table."""
+    Cc = pe.shape[-1]
+    patch = pe[:, 1:].reshape(1, g0, g0, Cc).permute(0, 3, 1, 2)
+    patch = F.interpolate(patch, size=(gh, gw), mode="bicubic", align_corners=False)
+    patch = patch.permute(0, 2, 3, 1).reshape(1, gh * gw, Cc)
+    return torch.cat((pe[:, :1], patch), dim=1)[0].contiguous()
+
+
 class _Affine(nn.Module):
     """weight (+ optional bias) holder; the attribute path gives the tensor its BEiT key name."""
 
@@ -177,11 +189,7 @@ class DiTEncoder(nn.Module):
         if hit is not None and hit[0] == key:
             return hit[1]
         with torch.no_grad():
-            Cc = pe.shape[-1]
-            patch = pe[:, 1:].reshape(1, g0, g0, Cc).permute(0, 3, 1, 2)
-            patch = F.interpolate(patch, size=(gh, gw), mode="bicubic", align_corners=False)
-            patch = patch.permute(0, 2, 3, 1).reshape(1, gh * gw, Cc)
-            table = torch.cat((pe[:, :1], patch), dim=1)[0].contiguous()
+            table = resample_position_table(pe, g0, gh, gw)
         self._pos_cache[(gh, gw)] = (key, table)
         return table
 
@@ -353,19 +361,12 @@ class DiTEncoder(nn.Module):
         """Train mode WITHOUT gradients (``model.train()`` under ``torch.no_grad()``): HF still applies stochastic depth
         (TF:360-378), which only the training forward implements.  With a drop-path rate of 0 (or one layer) train and
         eval arithmetic coincide and the inference kernels of ``compute_dtype`` run; otherwise the training forward runs
-        where its geometry allows (the position table's own grid, at most 256 tokens) and anything else is refused
-        rather than silently computed without stochastic depth."""
+        (any grid since round 3); the fp8 build refuses rather than silently computing without stochastic depth."""
         cfg = self.config
         if cfg.drop_path_rate <= 0.0 or cfg.num_hidden_layers < 2:
             return False
         if self.compute_dtype == "fp8":
             raise NotImplementedError("train mode with stochastic depth on the fp8 (inference-only) build: call .eval()")
-        g0 = cfg.image_size // cfg.patch_size
-        gh, gw = H // cfg.patch_size, W // cfg.patch_size
-        if (gh, gw) != (g0, g0) or gh * gw + 1 > 256:
-            raise NotImplementedError(f"train mode with stochastic depth (drop_path_rate={cfg.drop_path_rate}) at a "
-                                      f"{gh}x{gw} grid: the training forward covers the position table's own grid with at most "
-                                      "256 tokens; call .eval() for inference at other sizes")
         return True
 
     # ---- forward -------------------------------------------------------------------------------------------------

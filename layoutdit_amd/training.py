@@ -48,9 +48,14 @@ class FlatState:
 
     def __init__(self, encoder, img_h: int, img_w: int):
         cfg = encoder.config
-        if (img_h // cfg.patch_size, img_w // cfg.patch_size) != (cfg.image_size // cfg.patch_size,) * 2:
-            raise NotImplementedError("training needs the input grid to be the position table's own grid "
-                                      f"({cfg.image_size}x{cfg.image_size}): the backward does not differentiate the bicubic resample")
+        g0 = cfg.image_size // cfg.patch_size
+        self.grid = (img_h // cfg.patch_size, img_w // cfg.patch_size)
+        # At the position table's own grid the embeddings.position_embeddings parameter is a view of the flat block like every
+        # other parameter.  At another grid (round 3) the block's `pos` slot holds the table RESAMPLED for that grid (TF:113-151,
+        # bicubic) - a derived tensor, refreshed from the parameter when it changes; the library differentiates with respect to
+        # the slot, and the resample's adjoint (torch autograd on the parameter-sized op) carries that gradient to the parameter.
+        self.native = self.grid == (g0, g0)
+        self.encoder_ref = encoder
         lib = _lib.load()
         self.lcfg = encoder._lcfg(img_h, img_w, cfg.taps)
         self.lcfg.dtype = _lib.DTYPE_BF16
@@ -75,7 +80,11 @@ class FlatState:
         bind(emb.patch_embeddings.projection.weight, self.offsets[0], "patch_w")
         bind(emb.patch_embeddings.projection.bias, self.offsets[1], "patch_b")
         bind(emb.cls_token, self.offsets[2], "cls")
-        bind(emb.position_embeddings, self.offsets[3], "pos")
+        self.pos_param = emb.position_embeddings
+        self.pos_off, self.pos_numel = self.offsets[3], (self.grid[0] * self.grid[1] + 1) * Cc
+        self._pos_synced = None
+        if self.native:
+            bind(emb.position_embeddings, self.offsets[3], "pos")
         for l, blk in enumerate(encoder.encoder.layer):
             o = dict(zip(_LAYER_SLOTS, self.offsets[4 + 14 * l: 4 + 14 * (l + 1)]))
             a = blk.attention.attention
@@ -129,7 +138,32 @@ class FlatState:
         return self.grads[self.layer_start[stage - 1]: self.layer_start[stage]]
 
     def version(self):
-        return tuple(p._version for _, p, _, _ in self.named)
+        return tuple(p._version for _, p, _, _ in self.named) + (self.pos_param._version,)
+
+    def sync_pos(self) -> None:
+        """Non-native grid: (re)fill the block's `pos` slot with the bicubic resample of the position parameter."""
+        if self.native:
+            return
+        key = (self.pos_param.data_ptr(), self.pos_param._version)
+        if self._pos_synced != key or self._dirty:
+            from .modeling.dit_encoder import resample_position_table
+            g0 = self.encoder_ref.config.image_size // self.encoder_ref.config.patch_size
+            with torch.no_grad():
+                table = resample_position_table(self.pos_param.detach(), g0, self.grid[0], self.grid[1])
+                self.params[self.pos_off: self.pos_off + self.pos_numel].copy_(table.reshape(-1))
+            self._pos_synced = key
+
+    def pos_param_grad(self, flat_grads: torch.Tensor) -> torch.Tensor:
+        """Gradient of the position PARAMETER from the gradient of the resampled table (non-native grid): the adjoint of the
+        bicubic resample, by torch autograd on the parameter-sized op (host-side plumbing, like the resample itself)."""
+        from .modeling.dit_encoder import resample_position_table
+        g0 = self.encoder_ref.config.image_size // self.encoder_ref.config.patch_size
+        d_table = flat_grads[self.pos_off: self.pos_off + self.pos_numel].view(-1, self.pos_param.shape[-1])
+        with torch.enable_grad():
+            pe = self.pos_param.detach().requires_grad_(True)
+            table = resample_position_table(pe, g0, self.grid[0], self.grid[1])
+            (g,) = torch.autograd.grad(table, pe, d_table)
+        return g
 
     def mark_dirty(self) -> None:
         """Tell the state that the flat block was written behind autograd's version counters (``p.data.copy_()``,
@@ -142,6 +176,7 @@ class FlatState:
         :meth:`mark_dirty`, or with ``force=True``.  ``.data`` writes bypass the version counter: call ``mark_dirty()``."""
         v = self.version()
         if force or self._dirty or v != self._packed_version:
+            self.sync_pos()
             with torch.cuda.device(self.device):
                 _lib.check(_lib.load().ldit_pack_train(C.byref(self.lcfg), self.params.data_ptr(), self.packed.data_ptr(),
                                                        self.packed.numel(), torch.cuda.current_stream(self.device).cuda_stream))
@@ -258,13 +293,16 @@ class _EncoderFn(torch.autograd.Function):
         st.backward(ctx.x, ctx.taps, d, ctx.drop, ctx.saved_acts, L, 0)
         ctx.saved_acts = None
         need = ctx.needs_input_grad[4:]
+        n_extra = 0 if st.native else 1
         if not any(need):
-            return (None,) * (4 + len(st.named))
+            return (None,) * (4 + len(st.named) + n_extra)
         # ONE copy of the flat gradient block (the library overwrites it on the next backward); the per-parameter gradients
         # handed to autograd are views of that copy
         flat = st.grads.clone()
         grads = tuple(flat[off: off + _numel(shape)].view(shape) if n else None
                       for (_, _, off, shape), n in zip(st.named, need))
+        if not st.native:           # the position parameter rides behind the named ones: gradient through the resample's adjoint
+            grads += (st.pos_param_grad(flat) if need[len(st.named)] else None,)
         return (None, None, None, None) + grads
 
 
@@ -278,7 +316,7 @@ def _numel(shape) -> int:
 def encoder_forward_autograd(encoder, x: torch.Tensor, taps: Sequence[int], drop_scales: Optional[torch.Tensor] = None):
     """Differentiable encoder forward; returns the list of tapped hidden states (fp32 ``[B, 1+P, C]``)."""
     st = flat_state(encoder, x.shape[2], x.shape[3])
-    params = [p for _, p, _, _ in st.named]
+    params = [p for _, p, _, _ in st.named] + ([] if st.native else [st.pos_param])
     return list(_EncoderFn.apply(st, x, tuple(taps), drop_scales, *params))
 
 
@@ -298,6 +336,10 @@ class TrainStep:
         h, w = img_size or (cfg.image_size, cfg.image_size)
         self.encoder, self.rank = encoder, rank
         self.state = flat_state(encoder, h, w)
+        if not self.state.native:
+            raise NotImplementedError("TrainStep (fused AdamW on the flat block) needs the input grid to be the position table's own: "
+                                      "at another grid the block's position slot is a derived (resampled) tensor, not a parameter; "
+                                      "use the autograd path (loss.backward() + torch.optim) there")
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.exp_avg = torch.zeros_like(self.state.params)
         self.exp_avg_sq = torch.zeros_like(self.state.params)
@@ -340,8 +382,19 @@ class TrainStep:
         return None
 
     @torch.no_grad()
-    def step(self, x: torch.Tensor, _timing: Optional[dict] = None, drop_scales: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+    def step(self, x: torch.Tensor, _timing: Optional[dict] = None, drop_scales: Optional[torch.Tensor] = None,
+             _trace: Optional[list] = None) -> List[torch.Tensor]:
+        """``_trace`` (tests): receives ``(what, stage, torch.cuda.Event)`` tuples recorded on the compute stream in host order -
+        ``"backward_done"`` after a stage's backward kernels, ``"allreduce_issued"`` after its bucket was handed to RCCL,
+        ``"waited"`` after the last ``wait()``, ``"adamw_done"`` - so the overlap structure can be asserted, not just claimed."""
         st = self.state
+
+        def mark(what: str, stage):
+            if _trace is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(st.device))
+                _trace.append((what, stage, ev))
+
         if not st.intact():
             raise RuntimeError("the encoder's parameters were re-homed after TrainStep was built (.to() / assign): rebuild it")
         B = x.shape[0]
@@ -358,18 +411,23 @@ class TrainStep:
         if self.comm:
             for stage in range(L, -1, -1):                       # one bucket per layer, reduced while the next layers run
                 st.backward(x, self.taps, dt, drop_scales, saved, stage, stage, _timing)
+                mark("backward_done", stage)
                 works.append(self._all_reduce(st.bucket(stage)))
+                mark("allreduce_issued", stage)
             for w in works:
                 if w is not None:
                     w.wait()
+            mark("waited", None)
         else:
             st.backward(x, self.taps, dt, drop_scales, saved, L, 0, _timing)
+            mark("backward_done", 0)
         self.steps += 1
         with torch.cuda.device(st.device):
             _lib.check(_lib.load().ldit_adamw_step(st.params.data_ptr(), st.grads.data_ptr(), self.exp_avg.data_ptr(),
                                                    self.exp_avg_sq.data_ptr(), st.numel, self.lr, self.betas[0], self.betas[1],
                                                    self.eps, self.wd, self.steps, 1.0 / self.world, st.packed.data_ptr(),
                                                    torch.cuda.current_stream(st.device).cuda_stream))
+        mark("adamw_done", None)
         st._packed_version = st.version()     # the update refreshed the bf16 mirror itself
         st._dirty = False
         # the update went through raw pointers: no tensor version moved, so every cache keyed on versions is stale now

@@ -91,7 +91,16 @@ def train_reference(cfg, weights: Dict[str, np.ndarray], x, dtaps: Sequence[np.n
     e = F.conv2d(xt, w["embeddings.patch_embeddings.projection.weight"], w["embeddings.patch_embeddings.projection.bias"],
                  stride=cfg.patch_size)
     e = e.flatten(2).transpose(1, 2)
-    h = torch.cat((w["embeddings.cls_token"].expand(B, -1, -1), e), dim=1) + w["embeddings.position_embeddings"]
+    pe = w["embeddings.position_embeddings"]
+    gh, gw = xt.shape[2] // cfg.patch_size, xt.shape[3] // cfg.patch_size
+    g0 = int(round((pe.shape[1] - 1) ** 0.5))
+    if (gh, gw) != (g0, g0):
+        # interpolate_pos_encoding, TF:113-151: bicubic resample (align_corners=False) of the patch part of the table, inside
+        # the graph - the gradient reaches the table through the resample's adjoint
+        patch = pe[:, 1:].reshape(1, g0, g0, C).permute(0, 3, 1, 2)
+        patch = F.interpolate(patch, size=(gh, gw), mode="bicubic", align_corners=False)
+        pe = torch.cat((pe[:, :1], patch.permute(0, 2, 3, 1).reshape(1, gh * gw, C)), dim=1)
+    h = torch.cat((w["embeddings.cls_token"].expand(B, -1, -1), e), dim=1) + pe
     out = {0: h} if 0 in taps else {}
     for l in range(cfg.num_hidden_layers):
         p = f"encoder.layer.{l}."

@@ -234,7 +234,7 @@ def test_train_step_layout_and_sizing_are_host_side():
     assert lib.ldit_train_saved_bytes(C.byref(lc32), 64) == 0 and "bf16" in lib.ldit_last_error().decode()      # fp32 build
     big = _cfg(cfgs.vit_large(), 512, 512)
     big.dtype = _lib.DTYPE_BF16
-    assert lib.ldit_train_saved_bytes(C.byref(big), 1) == 0 and "256" in lib.ldit_last_error().decode()           # N = 1025
+    assert lib.ldit_train_saved_bytes(C.byref(big), 1) > 0                  # N = 1025 trains since round 3 (blocked attention backward)
     # train mode of the module without a GPU fails loudly, it does not fall back
     from layoutdit_amd import training
     m = DiTEncoder(cfgs.vit_micro(), compute_dtype="bf16").train()

@@ -170,6 +170,23 @@ def test_train_step_bucketed_all_reduce_over_rccl_one_rank():
         "    st.step(x); st.step(x)\n"
         "    torch.cuda.synchronize(); out.append((st.state.grads.clone(), st.flat_params.clone()))\n"
         "assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])\n"
+        # the overlap structure, asserted on the GPU timeline (events on the compute stream, recorded in host order): bucket l is
+        # handed to RCCL BEFORE stage l-1's backward kernels are even enqueued, so the collective has that whole backward stage
+        # to run under; nothing waits until every stage has been enqueued; AdamW comes after the last wait
+        "m = DiTEncoder(cfg, compute_dtype='bf16').load_numpy(synth.synth_weights(cfg, 3)).to('cuda:0').train()\n"
+        "st = training.TrainStep(m, r, lr=1e-3, dtaps=dt, drop_path_rate=0.0, img_size=(64, 64), force_comm=True)\n"
+        "tr = []\n"
+        "st.step(x, _trace=tr); torch.cuda.synchronize()\n"
+        "L = cfg.num_hidden_layers\n"
+        "names = [(w, s) for w, s, _ in tr]\n"
+        "want = []\n"
+        "for s in range(L, -1, -1): want += [('backward_done', s), ('allreduce_issued', s)]\n"
+        "assert names == want + [('waited', None), ('adamw_done', None)], names\n"
+        "ev = {(w, s): e for w, s, e in tr}\n"
+        "for s in range(L, 0, -1):\n"
+        "    under = ev[('allreduce_issued', s)].elapsed_time(ev[('backward_done', s - 1)])\n"
+        "    assert under > 0.0, (s, under)      # stage s-1's backward ran AFTER bucket s was with RCCL\n"
+        "assert ev[('allreduce_issued', 0)].elapsed_time(ev[('adamw_done', None)]) > 0.0\n"
         "dp.finalize(r); print('rccl-train-ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),

@@ -154,8 +154,8 @@ def test_error_behaviour():
     m.train()
     out = m(torch.zeros(1, 3, 64, 64, device=DEV))             # round 3: the f32 build trains (bf16 operands, fp32 master weights)
     assert out.hidden_states[3].requires_grad
-    with pytest.raises(NotImplementedError, match="position table's own grid"):
-        m(torch.zeros(1, 3, 96, 96, device=DEV))               # no backward of the bicubic position resample
+    out = m(torch.zeros(1, 3, 96, 96, device=DEV))             # ... also at a grid that resamples the position table (round 3)
+    assert out.hidden_states[3].requires_grad and tuple(out.hidden_states[3].shape) == (1, 37, cfg.hidden_size)
     for p in m.parameters():
         p.requires_grad_(False)
     assert m(torch.zeros(1, 3, 64, 64, device=DEV)).hidden_states[3] is not None   # frozen backbone in train mode is fine

@@ -60,7 +60,7 @@ def _attention_ref(q, k, v, do, H):
     return o.detach(), lse2.detach(), q.grad, k.grad, v.grad
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 256, 2), (3, 17, 2), (2, 33, 1)])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 256, 2), (3, 17, 2), (2, 33, 1), (1, 257, 2), (2, 300, 1), (1, 1025, 2), (1, 512, 1)])
 def test_attention_forward_lse_and_backward(B, N, H):
     lib = _lib.load()
     D, HD = 64, H * 64
@@ -85,10 +85,28 @@ def test_attention_forward_lse_and_backward(B, N, H):
         assert rel_l2(a, r.numpy()) < 1.5e-2, name
 
 
-def test_attention_backward_rejects_long_sequences():
+def test_attention_backward_long_sequences_are_reproducible():
+    """N > 256 takes the blocked form (a workgroup per 256-row block and role; every sum inside one wave): two runs agree bit
+    for bit, and every row of dq | dk | dv is written."""
     lib = _lib.load()
-    rc = lib.ldit_attention_bwd_bf16(16, 16, 16, 16, 16, 16, 16, 16, 16, 1, 1025, 1, 64, 192, 64, 64, 192, 0.125, None)
-    assert rc == _lib.LDIT_EUNSUPPORTED and b"256" in lib.ldit_last_error()
+    B, N, H, D = 2, 600, 2, 64
+    HD = H * D
+    qkv = _bf(_rand(7, B, N, 3 * HD)).to(DEV)
+    do = _bf(_rand(8, B, N, HD, scale=0.5)).to(DEV)
+    q, k, v = qkv[..., :HD], qkv[..., HD:2 * HD], qkv[..., 2 * HD:]
+    o = torch.empty((B, N, HD), dtype=BF, device=DEV)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=DEV)
+    _lib.check(lib.ldit_attention_fwd_lse_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, D,
+                                               3 * HD, 3 * HD, 3 * HD, HD, D ** -0.5, _stream()))
+    outs = []
+    for _ in range(2):
+        dqkv = torch.full((B, N, 3 * HD), float("nan"), dtype=BF, device=DEV)
+        _lib.check(lib.ldit_attention_bwd_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                                               dqkv.data_ptr(), dqkv[..., HD:].data_ptr(), dqkv[..., 2 * HD:].data_ptr(), B, N, H, D,
+                                               3 * HD, HD, HD, 3 * HD, D ** -0.5, _stream()))
+        outs.append(dqkv)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs[0].float()).all()) and torch.equal(outs[0], outs[1])
 
 
 # ---- LayerNorm backward -----------------------------------------------------------------------------------------------------
@@ -431,11 +449,8 @@ def test_train_mode_without_grad_applies_stochastic_depth(monkeypatch):
     m8 = DiTEncoder(cfg, compute_dtype="fp8").load_numpy(w).to(DEV).train()
     with pytest.raises(NotImplementedError, match="inference only|fp8"):
         m8(torch.from_numpy(x).to(DEV))
-    # a grid the training forward does not cover is refused, not silently computed without stochastic depth ...
+    # with a drop-path rate of 0 train == eval arithmetic: the inference kernels of the build run (any grid)
     x96 = torch.from_numpy(synth.synth_images(2, 96, 96, seed=5, kind="uniform")).to(DEV)
-    with torch.no_grad(), pytest.raises(NotImplementedError, match="eval"):
-        m(x96)
-    # ... and with a drop-path rate of 0 train == eval arithmetic: the inference kernels of the build run
     m32.config.drop_path_rate = 0.0
     with torch.no_grad():
         a = m32(x96).hidden_states[cfg.taps[-1]]
@@ -469,6 +484,68 @@ def test_f32_build_trains_on_the_bf16_kernels_like_the_reference_cpu_branch(monk
         h = m(torch.from_numpy(x).to(DEV)).hidden_states[cfg.taps[-1]]
     ref_taps, _ = train_reference(cfg, w, x, dtaps, drop_scales=None)
     assert rel_l2(h.cpu().numpy(), ref_taps[-1]) < 2e-5
+
+
+@pytest.mark.parametrize("size,B", [(96, 3), (272, 2)])
+def test_training_at_other_grids_and_beyond_256_tokens(size, B):
+    """Round 3: the train path is no longer tied to the position table's own grid or to 256 tokens (ViT-L/16 at 512 x 512 = 1025
+    tokens trains).  Micro geometry at 96 x 96 (grid 6 x 6: the position table is resampled bicubically, TF:113-151, and its
+    gradient travels back through the resample's adjoint) and at 272 x 272 (290 tokens: the blocked attention backward):
+    every parameter gradient, embeddings.position_embeddings included, against the float64 autograd oracle."""
+    cfg = cfgs.vit_micro()
+    cfg.drop_path_rate = 0.0
+    w = synth.synth_weights(cfg, 3)
+    x = synth.synth_images(B, size, size, seed=5, kind="uniform")
+    N = cfg.tokens(size, size)
+    dtaps = upstream(cfg, B, N, 9)
+    m = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(w).to(DEV).train()
+    out = m(torch.from_numpy(x).to(DEV))
+    sum((out.hidden_states[t] * torch.from_numpy(d).to(DEV)).sum() for t, d in zip(cfg.taps, dtaps)).backward()
+    torch.cuda.synchronize()
+    ref_taps, ref = train_reference(cfg, w, x, dtaps)
+    for t, r in zip(cfg.taps, ref_taps):
+        assert rel_l2(out.hidden_states[t].detach().cpu().numpy(), r) < 2e-2
+    got = {k: p.grad for k, p in m.state_dict(keep_vars=True).items() if p.grad is not None}
+    assert tuple(got["embeddings.position_embeddings"].shape) == (1, 17, cfg.hidden_size)
+    for k, r in ref.items():
+        if k.endswith("key.bias"):
+            continue
+        assert k in got, k
+        assert rel_l2(got[k].cpu().numpy(), r) < GRAD_TOL, (k, rel_l2(got[k].cpu().numpy(), r))
+    with pytest.raises(NotImplementedError, match="position table's own"):
+        training.TrainStep(m, lr=1e-3, img_size=(size, size))          # the fused step updates the flat block: native grid only
+
+
+def test_vit_large_512_trains():
+    """ViT-L/16 at 512 x 512 (BASELINE configs[3]'s geometry, 1025 tokens, resampled 32 x 32 position grid) through
+    loss.backward(): sampled parameter gradients against the float64 autograd oracle (one image: the CPU oracle run is the
+    long pole of this test), bit-reproducible."""
+    cfg = cfgs.vit_large()
+    cfg.drop_path_rate = 0.0
+    w = synth.synth_weights(cfg, 3)
+    x = synth.synth_images(1, 512, 512, seed=1234)
+    N = cfg.tokens(512, 512)
+    assert N == 1025
+    dtaps = upstream(cfg, 1, N, 11)
+    m = DiTEncoder(cfg, compute_dtype="bf16").load_numpy(w).to(DEV).train()
+    xd = torch.from_numpy(x).to(DEV)
+    dd = [torch.from_numpy(d).to(DEV) for d in dtaps]
+    out = m(xd)
+    sum((out.hidden_states[t] * d).sum() for t, d in zip(cfg.taps, dd)).backward()
+    torch.cuda.synchronize()
+    first = m._flat_state.grads.clone()
+    got = {k: p.grad.clone() for k, p in m.state_dict(keep_vars=True).items() if p.grad is not None}
+    for p in m.parameters():
+        p.grad = None
+    out = m(xd)
+    sum((out.hidden_states[t] * d).sum() for t, d in zip(cfg.taps, dd)).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(m._flat_state.grads, first)
+    _, ref = train_reference(cfg, w, x, dtaps)
+    for k in ("embeddings.position_embeddings", "embeddings.patch_embeddings.projection.weight", "encoder.layer.0.attention.attention.query.weight",
+              "encoder.layer.11.attention.attention.key.weight", "encoder.layer.23.intermediate.dense.weight", "encoder.layer.5.lambda_1",
+              "encoder.layer.17.layernorm_after.bias", "encoder.layer.23.attention.output.dense.bias"):
+        assert rel_l2(got[k].cpu().numpy(), ref[k]) < GRAD_TOL, (k, rel_l2(got[k].cpu().numpy(), ref[k]))
 
 
 def test_caches_follow_parameter_updates_that_bypass_version_counters():
