@@ -252,21 +252,29 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_fp8_mfma(con
                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wb[j], xa[i], acc[i][j], 0, 0, 0, 0, 0, 0);
         };
         i32x8 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
+        // Round 3: the DMA of tile kt+2 is issued right BEHIND the hand-over barrier of iteration kt (stage `cur` is free there:
+        // every wave's last fragments of tile kt are in registers) and waited for at the NEXT hand-over - a whole k-tile of MFMA
+        // time (2048 cycles per SIMD) to land.  Rounds 1-2 issued tile kt+1 at the top of iteration kt and waited for it half a
+        // k-tile later: shorter than an L2 / Infinity-Cache round trip under load, so every k-tile stalled on its own DMA.
         issue(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tile has landed before anybody reads it
-        __syncthreads();
+        issue(1, (nk > 1 ? 1 : 0) * BKE);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");      // tile 0 landed; tile 1's NLD pieces stay in flight
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         load_frags(0, 0, xa0, wb0);
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
-            const int knext = (kt + 1 < nk ? kt + 1 : nk - 1) * BKE;
+            const int k2 = (kt + 2 < nk ? kt + 2 : nk - 1) * BKE;
             load_frags(cur, 1, xa1, wb1);
-            issue(cur ^ 1, knext);
             mfma_chunk(xa0, wb0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: do not rely on hipcc to drain the LDS-DMA in front of the barrier
-            __syncthreads();   // hand-over: tile kt+1 landed in every wave, stage cur released (its last reads are in xa1/wb1)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile kt+1 landed; own reads of stage cur retired
+            __builtin_amdgcn_s_barrier();   // hand-over: tile kt+1 visible to every wave, stage cur released
+            asm volatile("" ::: "memory");
+            issue(cur, k2);                 // tile kt+2 -> stage cur (a clamped re-fetch on the last two iterations, never read)
             load_frags(cur ^ 1, 0, xa0, wb0);
             mfma_chunk(xa1, wb1);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches must not outlive the LDS allocation
     }
 
     const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
