@@ -278,7 +278,8 @@ class _EncoderFn(torch.autograd.Function):
         state.repack()
         saved = state.new_saved(x.shape[0])
         outs = state.forward(x, taps, drop_scales, saved)
-        ctx.state, ctx.x, ctx.taps, ctx.drop, ctx.saved_acts = state, x, taps, drop_scales, saved
+        ctx.state, ctx.taps, ctx.drop, ctx.saved_acts = state, taps, drop_scales, saved
+        ctx.save_for_backward(x)               # the pixels: needed by the patch-embedding wgrad
         return tuple(outs)
 
     @staticmethod
@@ -290,7 +291,8 @@ class _EncoderFn(torch.autograd.Function):
                                "run the forward again")
         d = [None if g is None else g.contiguous().to(torch.float32) for g in dtaps]
         L = st.lcfg.layers
-        st.backward(ctx.x, ctx.taps, d, ctx.drop, ctx.saved_acts, L, 0)
+        (x,) = ctx.saved_tensors
+        st.backward(x, ctx.taps, d, ctx.drop, ctx.saved_acts, L, 0)
         ctx.saved_acts = None
         need = ctx.needs_input_grad[4:]
         n_extra = 0 if st.native else 1

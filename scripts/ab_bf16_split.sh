@@ -4,6 +4,8 @@
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
 cd $ROOT
 cp layoutdit_amd/libldit_hip.so /tmp/split.so
+# whatever ends this script (interrupt, error, normal exit), the production library is put back
+trap 'cp /tmp/split.so "$ROOT/layoutdit_amd/libldit_hip.so"' EXIT INT TERM
 for round in 1 2 3; do
   for v in split nosplit; do
     if [ $v = split ]; then cp /tmp/split.so layoutdit_amd/libldit_hip.so; else cp layoutdit_amd/csrc/build/libldit_hip_nosplit.so layoutdit_amd/libldit_hip.so; fi
