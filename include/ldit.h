@@ -199,7 +199,9 @@ int ldit_linear_bf16(const void *X, int64_t lda, const void *W, const void *bias
                      ldit_stream stream);
 
 /* softmax(Q K^T * scale) V per head; Q, K, V bf16 [B, N, H*D] token-major (row strides in bf16 elements), O bf16;
- * fp32 softmax and accumulation.  D == 64. */
+ * fp32 softmax and accumulation.  D == 64.  scale == 0 means "Q is already multiplied by scale * log2(e)" (what the packed
+ * inference path delivers: ldit_pack_weights folds that factor into W_q / b_q of the bf16 and fp8 builds): the scores are then
+ * exp2-domain exponents and the kernel subtracts the running maximum on the matrix pipe instead of per element. */
 int ldit_attention_bf16(const void *Q, const void *K, const void *V, void *O, int64_t B, int64_t N, int64_t H, int64_t D,
                         int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, ldit_stream stream);
 

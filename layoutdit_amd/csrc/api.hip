@@ -149,7 +149,7 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
                                                         nullptr, nullptr, 0.f, 0.f, sc + 0, F32(pl.sw_qkv), nullptr, stream));
             LDIT_RUN(probe, LDIT_K_ATTENTION,
                      launch_attention_bf16_fp8out(bb, bb + 2 * (size_t)C, bb + 4 * (size_t)C, y8, batch, g.T, g.H, g.D, 3 * C, 3 * C,
-                                                  3 * C, C, scale, sc + 2, stream));
+                                                  3 * C, C, 0.0f /* q pre-scaled at pack time */, sc + 2, stream));
             LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_fp8(y8, C, P + pl.wo, F32(pl.bo), h, C, M, C, C, EPI_SCALE_RESID, F32(pl.lam1), h,
                                                         nullptr, 0.f, 0.f, sc + 2, F32(pl.sw_o), nullptr, stream));
             LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_fp8out(h, F32(pl.ln2_w), F32(pl.ln2_b), y8, M, C, cfg->ln_eps, sc + 4, stream));
@@ -182,7 +182,7 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
                                                          nullptr, nullptr, nullptr, stream));
             LDIT_RUN(probe, LDIT_K_ATTENTION,
                      launch_attention_bf16(bb, bb + 2 * (size_t)C, bb + 4 * (size_t)C, yb, batch, g.T, g.H, g.D, 3 * C, 3 * C, 3 * C,
-                                           C, scale, stream));
+                                           C, 0.0f /* q pre-scaled at pack time */, stream));
             LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16(yb, C, P + pl.wo, F32(pl.bo), h, C, M, C, C, EPI_SCALE_RESID, F32(pl.lam1),
                                                          h, nullptr, stream));
             LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bf16out(h, F32(pl.ln2_w), F32(pl.ln2_b), yb, M, C, cfg->ln_eps, stream));
@@ -240,16 +240,20 @@ int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, 
     };
     // matrix [rows, cols] at element offset elt_off of the block at `off`: fp32 copy, -> bf16, or -> fp8 codes with one
     // scale per row written to the fp32 vector at sw_off (+ row0)
+    // `mul` (bf16 / fp8 builds only): a factor folded into the matrix as it is packed (bf16: into the values before the one
+    // rounding; fp8: into the per-row scales).  Used for W_q: q' = (scale log2 e) q, so that the attention kernel's scores
+    // are exp2-domain exponents (attention_bf16.hip, PRE) - the same single rounding of q as before, no extra error.
     auto put_mat = [&](size_t off, size_t elt_off, const void *src, size_t rows, size_t cols, size_t sw_off, size_t row0,
-                       const char *what) -> int {
+                       const char *what, float mul = 1.0f) -> int {
         if (!src) return fail(LDIT_EINVAL, "weights: %s is null", what);
         if (!bf16 && !fp8) return put(off + elt_off * 4, src, rows * cols, what);
         if (!aligned16(src)) return fail(LDIT_EINVAL, "weights: %s must be 16-byte aligned", what);
         if (fp8)
             return launch_quant_rows_fp8(static_cast<const float *>(src), P + off + elt_off,
-                                         reinterpret_cast<float *>(P + sw_off) + row0, (int)rows, (int)cols, stream);
-        return launch_cvt_bf16(static_cast<const float *>(src), P + off + elt_off * 2, rows * cols, stream);
+                                         reinterpret_cast<float *>(P + sw_off) + row0, (int)rows, (int)cols, stream, mul);
+        return launch_cvt_bf16(static_cast<const float *>(src), P + off + elt_off * 2, rows * cols, stream, mul);
     };
+    const float qfold = (bf16 || fp8) ? (1.0f / sqrtf((float)g.D)) * 1.44269504088896340736f : 1.0f;
     const size_t C = g.C, F = g.F;
     LDIT_TRY(put(pm.patch_w, w->patch_w, C * g.Kp, "patch_w"));
     LDIT_TRY(put(pm.patch_b, w->patch_b, C, "patch_b"));
@@ -261,12 +265,12 @@ int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, 
         LDIT_TRY(put(pl.ln1_w, s.ln1_w, C, "ln1_w"));
         LDIT_TRY(put(pl.ln1_b, s.ln1_b, C, "ln1_b"));
         if (fp8) LDIT_HIP_CHECK(hipMemsetAsync(P + pl.scales, 0, 8 * sizeof(float), stream));
-        LDIT_TRY(put_mat(pl.wqkv, 0, s.wq, C, C, pl.sw_qkv, 0, "wq"));
+        LDIT_TRY(put_mat(pl.wqkv, 0, s.wq, C, C, pl.sw_qkv, 0, "wq", qfold));
         LDIT_TRY(put_mat(pl.wqkv, C * C, s.wk, C, C, pl.sw_qkv, C, "wk"));
         LDIT_TRY(put_mat(pl.wqkv, 2 * C * C, s.wv, C, C, pl.sw_qkv, 2 * C, "wv"));
         if (!s.bq || !s.bv) return fail(LDIT_EINVAL, "weights: bq / bv is null");
         LDIT_TRY(launch_pack_qkv_bias(static_cast<const float *>(s.bq), static_cast<const float *>(s.bv),
-                                      reinterpret_cast<float *>(P + pl.bqkv), g.C, stream));
+                                      reinterpret_cast<float *>(P + pl.bqkv), g.C, stream, qfold));
         LDIT_TRY(put_mat(pl.wo, 0, s.wo, C, C, pl.sw_o, 0, "wo"));
         LDIT_TRY(put(pl.bo, s.bo, C, "bo"));
         LDIT_TRY(put(pl.lam1, s.lam1, C, "lam1"));

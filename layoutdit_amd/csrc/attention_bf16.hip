@@ -63,7 +63,13 @@ __device__ __forceinline__ void glds16_sbase(const void *ubase, unsigned voff_by
 }
 
 // OUT_FP8: O is written as fp8 e4m3 codes of o / *qscale (operand of the fp8 o_proj GEMM), ldo in elements.
-template <int KT, int NW, bool OUT_FP8>
+// PRE (round 3): Q arrives already multiplied by scale * log2(e) (the packed inference path folds that factor into W_q / b_q at
+// pack time: api.hip, ldit_pack_weights), so a raw score IS its exp2-domain exponent, and the running maximum is subtracted
+// BY THE MATRIX PIPE: one extra MFMA step per key tile with an all-ones A column and B = (-m_hi, -m_lo) (the maximum split into
+// two bf16 so that 2^-17 |m| is all it loses) initialises the S^T accumulators with -m_run.  p = exp2(S') then needs no
+// per-element FMA: 32 of the ~180 VALU instructions of a chunk, on a kernel whose four waves per SIMD saturate instruction
+// issue (PMC: SQ_ACTIVE_INST_ANY x 4 waves = 1.07 of the SIMD's cycles; MFMA pipe 32 % busy).
+template <int KT, int NW, bool OUT_FP8, bool PRE>
 __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const bf16_t *__restrict__ Q, const bf16_t *__restrict__ K,
                                                              const bf16_t *__restrict__ V, void *__restrict__ Ov,
                                                              int N, int H, int ldq, int ldk, int ldv, int ldo,
@@ -108,23 +114,21 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
     // in scalar registers, so issuing a chunk costs no vector address arithmetic (round 2 recomputed the clamp, the row
     // product and a 64-bit add per piece: ~30 VALU instructions per chunk on a kernel that is VALU-issue bound).  Only a chunk
     // that reaches past key N-1 (the short last one) takes the clamped path (rows past N = duplicates of the last key).
-    unsigned koff[PPW], voff[PPW];                      // element offsets
-#pragma unroll
-    for (int u = 0; u < PPW; ++u) {
-        const int piece = wave + NW * u, krow = 8 * piece + kkey;
-        koff[u] = (unsigned)krow * (unsigned)ldk + 8u * ((lane & 7) ^ ((krow >> 1) & 7));     // (x2 = bytes at the use)
-        voff[u] = (unsigned)(8 * piece + vkey) * (unsigned)ldv + (unsigned)vd;
-    }
+    // (piece u of a wave is 8 NW keys further down: the XOR swizzle term (krow >> 1) & 7 does not change, so ONE offset per
+    // operand serves every piece - the step goes into the scalar base)
+    static_assert((8 * NW) % 16 == 0, "pieces of one wave must share the swizzle phase");
+    const unsigned koff = (unsigned)(8 * wave + kkey) * (unsigned)ldk + 8u * ((lane & 7) ^ (((8 * wave + kkey) >> 1) & 7));   // elements
+    const unsigned voff = (unsigned)(8 * wave + vkey) * (unsigned)ldv + (unsigned)vd;
     auto issue = [&](int stage, int c0) {
         char *kb = smem + stage * STAGE, *vb = kb + HALF;
         if (c0 + KC <= N) {                              // wave-uniform
-            const bf16_t *kbase = Kh + (size_t)c0 * ldk, *vbase = Vh + (size_t)c0 * ldv;
             const unsigned kdst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)kb));
 #pragma unroll
             for (int u = 0; u < PPW; ++u) {
                 const int piece = wave + NW * u;
-                glds16_sbase(kbase, 2u * koff[u], kdst + piece * 1024);
-                glds16_sbase(vbase, 2u * voff[u], kdst + HALF + piece * 1024);
+                const bf16_t *kbase = Kh + (size_t)(c0 + 8 * NW * u) * ldk, *vbase = Vh + (size_t)(c0 + 8 * NW * u) * ldv;
+                glds16_sbase(kbase, 2u * koff, kdst + piece * 1024);
+                glds16_sbase(vbase, 2u * voff, kdst + HALF + piece * 1024);
             }
             return;
         }
@@ -144,9 +148,17 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
     f32x16 o[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { o[0][e] = 0.0f; o[1][e] = 0.0f; }
-    float m_run = -INFINITY, l_run = 0.0f;
-    const float c = scale * 1.44269504088896340736f;     // softmax in the exp2 domain
-    const float lazy = 8.0f / c;                         // deferred-rescale threshold in raw-score units (2^8 in the exp2 domain)
+    float m_run = PRE ? 0.0f : -INFINITY, l_run = 0.0f;
+    const float c = scale * 1.44269504088896340736f;     // softmax in the exp2 domain (PRE: already inside q)
+    const float lazy = PRE ? 8.0f : 8.0f / c;            // deferred-rescale threshold in score units (2^8 in the exp2 domain)
+    // PRE: operands of the extra MFMA step.  A = 1 at k = 0, 1 for every key row; B = (-m_hi, -m_lo) at k = 0, 1 of the lane's
+    // query (k = 8 h + j: only the h = 0 half carries them).
+    // (the step runs on v_mfma_f32_32x32x8_bf16 - lane (row, h) supplies k = 4 h + j, j < 4 - so its operands are two registers
+    // each: A = all ones, B = (-m_hi, -m_lo, 0, 0) in the h = 0 half, zeros in the other)
+    // (Row sums on the matrix pipe - an all-ones A operand per 16-key step - were built and measured: 112.5 us against 106.2 us
+    // at N = 1025; four more MFMAs per chunk cost more than the 16 v_pk_add_f32 they replace.  Not kept.)
+    bf16x4 ones4 = {(bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f, (bf16_t)1.0f};
+    bf16x4 mfrag = {(bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f};
     const int sw = (c32 >> 1) & 7;
     // transposing read: lane 4q+p of a 16-lane group addresses key q, d 4p..4p+3 of the group's 16 columns
     const int vlane = 64 * ((lane & 15) >> 2) + 32 * ((lane >> 4) & 1) + 8 * (lane & 3) + 512 * h;
@@ -188,10 +200,15 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
                     const char *kr = Ks + (kt * 32 + c32) * KROWB;
+                    if (PRE) {
+                        union { bf16x4 f; s16x4 v; } ua, ub;
+                        ua.f = ones4; ub.f = mfrag;
+                        s[kt] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(ua.v, ub.v, zero16, 0, 0, 0);      // = -m_run
+                    }
 #pragma unroll
                     for (int st = 0; st < 4; ++st) {
                         const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kr + (((2 * st + h) ^ sw) * 16));
-                        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], st ? s[kt] : zero16, 0, 0, 0);
+                        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], (PRE || st) ? s[kt] : zero16, 0, 0, 0);
                     }
                 }
                 ATT_STAMP(t3);
@@ -214,6 +231,40 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
                 // domain (always on the first chunk, m_run = -inf).  Until then p = exp2(c s - c m_run) may exceed 1 by up
                 // to 2^8 - harmless in fp32 sums and in bf16 P (a power-of-two scale of the same mantissas) - and the 32
                 // accumulator multiplies, the alpha exp2 and the l rescale are skipped behind a wave-uniform branch.
+                float lsum = 0.0f;
+                if constexpr (PRE) {
+                    // s holds S' = score - m_run.  The maximum moves on the first chunk (m_run = 0 there: whatever the scores
+                    // are, they are re-based on their own maximum) and when a chunk beats it by 2^8.  Everything still at the
+                    // old maximum is moved exactly once: O, the row sum, THIS chunk's S' and the MFMA operand that carries m.
+                    const bool grow = ci == 0 || mx > lazy;
+                    if (__builtin_amdgcn_ballot_w64(grow)) {
+                        // the new maximum as the sum of two bf16 (what the extra MFMA step can carry); d = the exact shift applied
+                        const float want = grow ? m_run + mx : m_run;
+                        const bf16_t hi = (bf16_t)(-want);
+                        const bf16_t lo = (bf16_t)(-want - (float)hi);
+                        const float m_new = -((float)hi + (float)lo);
+                        const float d = m_new - m_run;                   // exactly 0 for lanes that keep m_run (same hi, lo)
+                        // first chunk: O and the row sum are zero, and exp2(-d) may overflow for very negative scores
+                        const float alpha = ci == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);
+                        m_run = m_new;
+                        if (h == 0) { mfrag[0] = hi; mfrag[1] = lo; }
+                        l_run *= alpha;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+#pragma unroll
+                        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) s[kt][r] -= d;
+                    }
+#pragma unroll
+                    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(s[kt][r]);
+                            s[kt][r] = pv;
+                            lsum += pv;
+                        }
+                } else {
                 const bool grow = mx > m_run + lazy;
                 if (__builtin_amdgcn_ballot_w64(grow)) {
                     const float m_new = grow ? mx : m_run;
@@ -224,7 +275,6 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
                     for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
                 }
                 const float mc = m_run * c;
-                float lsum = 0.0f;
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -233,6 +283,7 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
                         s[kt][r] = pv;
                         lsum += pv;
                     }
+                }
                 l_run += lsum;
                 ATT_STAMP(t4);
                 // ---- O^T += V^T . P^T -----------------------------------------------------------------------------------
@@ -297,7 +348,7 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
     const int qrow = qt * 32 + c32;
     // train step: log2-domain log-sum-exp of the scaled scores, L2 = log2 sum_k exp2(c s_k) = m c + log2 l, so that the
     // backward recomputes p = exp2(c s - L2) with no row maximum (layout [B, H, N])
-    if (lse && h == 0 && qrow < N) lse[((size_t)b * H + head) * N + qrow] = __builtin_fmaf(m_run, c, __builtin_amdgcn_logf(l));
+    if (lse && h == 0 && qrow < N) lse[((size_t)b * H + head) * N + qrow] = (PRE ? m_run : m_run * c) + __builtin_amdgcn_logf(l);
     if (OUT_FP8) {
         if (qrow < N) {
             unsigned char *op = static_cast<unsigned char *>(Ov) + (tok0 + qrow) * ldo + head * 64 + 4 * h;
@@ -345,9 +396,11 @@ static int launch_attn(const void *Q, const void *K, const void *V, void *O, int
     };
     // LDS = two stages of (K image + V image).  64-key chunks: 32 KB and 128 VGPRs -> four workgroups per CU (four waves per
     // SIMD), measured 8-10 % faster than 128-key chunks at two per CU (LDIT_ATTN_BF16_KT=4) on N = 197 and N = 1025.
-    static std::atomic<unsigned long long> set2{0}, set4{0};      // per-device bookkeeping (ensure_dynamic_lds)
-    if (kt4) LDIT_TRY_RC(go(attention_bf16<4, NW, OUT_FP8>, 2 * 2 * 4 * 32 * KROWB, set4));
-    else LDIT_TRY_RC(go(attention_bf16<2, NW, OUT_FP8>, 2 * 2 * 2 * 32 * KROWB, set2));
+    // scale == 0: Q is pre-multiplied by scale * log2(e) (PRE, the packed inference path); otherwise the factor is applied here.
+    static std::atomic<unsigned long long> set2{0}, set4{0}, set2p{0};      // per-device bookkeeping (ensure_dynamic_lds)
+    if (scale == 0.0f) LDIT_TRY_RC(go(attention_bf16<2, NW, OUT_FP8, true>, 2 * 2 * 2 * 32 * KROWB, set2p));
+    else if (kt4) LDIT_TRY_RC(go(attention_bf16<4, NW, OUT_FP8, false>, 2 * 2 * 4 * 32 * KROWB, set4));
+    else LDIT_TRY_RC(go(attention_bf16<2, NW, OUT_FP8, false>, 2 * 2 * 2 * 32 * KROWB, set2));
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }

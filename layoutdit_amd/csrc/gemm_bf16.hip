@@ -376,15 +376,16 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
 }
 
 // fp32 -> bf16 (round to nearest even), n elements, 4 per thread
-__global__ void __launch_bounds__(256) cvt_f32_bf16(const float *__restrict__ src, bf16_t *__restrict__ dst, size_t n)
+// (mul: pack-time factor - 1, or scale * log2 e on W_q for the pre-scaled attention; the product is rounded ONCE)
+__global__ void __launch_bounds__(256) cvt_f32_bf16(const float *__restrict__ src, bf16_t *__restrict__ dst, size_t n, float mul)
 {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 3 < n) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(src + i);
-        const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        const bf16x4 o = {(bf16_t)(v[0] * mul), (bf16_t)(v[1] * mul), (bf16_t)(v[2] * mul), (bf16_t)(v[3] * mul)};
         *reinterpret_cast<bf16x4 *>(dst + i) = o;
     } else {
-        for (size_t k = i; k < n; ++k) dst[k] = (bf16_t)src[k];
+        for (size_t k = i; k < n; ++k) dst[k] = (bf16_t)(src[k] * mul);
     }
 }
 
@@ -455,11 +456,11 @@ static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const flo
     }
 }
 
-int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream)
+int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream, float mul)
 {
     if (n == 0) return LDIT_OK;
     hipLaunchKernelGGL(cvt_f32_bf16, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream, src,
-                       static_cast<bf16_t *>(dst), n);
+                       static_cast<bf16_t *>(dst), n, mul);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }

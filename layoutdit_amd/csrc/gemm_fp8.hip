@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(256) amax_f32(const float *__restrict__ src, s
 // Per-output-channel scales cost nothing in the GEMM (one more factor on the accumulator in the epilogue) and keep
 // a few large rows from flattening all the others.
 __global__ void __launch_bounds__(256) quant_rows_fp8(const float *__restrict__ W, unsigned char *__restrict__ dst,
-                                                      float *__restrict__ scales, int N, int K)
+                                                      float *__restrict__ scales, int N, int K, float mul)
 {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
@@ -447,8 +447,10 @@ __global__ void __launch_bounds__(256) quant_rows_fp8(const float *__restrict__ 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    // (mul: pack-time factor on the row - scale * log2 e on W_q for the pre-scaled attention - carried by the row's scale: the
+    // codes are those of the unscaled row)
     const float sc = fmaxf(m, 1e-30f) * (1.0f / 448.0f), inv = 1.0f / sc;
-    if (lane == 0) scales[row] = sc;
+    if (lane == 0) scales[row] = sc * mul;
     unsigned *d4 = reinterpret_cast<unsigned *>(dst + (size_t)row * K);
     for (int i = lane; i < K / 4; i += 64) {
         const f32x4 v = w4[i];
@@ -521,12 +523,12 @@ int launch_quant_fp8(const float *src, void *dst, size_t n, float inv_scale, con
     return LDIT_OK;
 }
 
-int launch_quant_rows_fp8(const float *W, void *dst, float *scales, int N, int K, hipStream_t stream)
+int launch_quant_rows_fp8(const float *W, void *dst, float *scales, int N, int K, hipStream_t stream, float mul)
 {
     if (N <= 0 || K <= 0 || (K & 3)) return fail(LDIT_EINVAL, "quant_rows_fp8: bad shape %d x %d", N, K);
     if (!W || !dst || !scales || !aligned16(W)) return fail(LDIT_EINVAL, "quant_rows_fp8: null or misaligned operand");
     hipLaunchKernelGGL(quant_rows_fp8, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, W, static_cast<unsigned char *>(dst),
-                       scales, N, K);
+                       scales, N, K, mul);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }

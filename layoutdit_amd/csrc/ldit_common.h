@@ -199,14 +199,14 @@ int launch_gemm_bf16_ex(const void *A, int lda, const void *W, const float *bias
                         const float *lam, const float *R, float *Y2, const GemmExtra &x, hipStream_t stream);
 int launch_gemm_bf16_tr(const void *A, int lda, bool a_reduction_major, const void *W, int ldw, const float *bias, void *Y, int ldy,
                         int M, int N, int K, int epi, const GemmExtra &x, hipStream_t stream);
-int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream);
+int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream, float mul = 1.0f);
 // fp8: the per-tensor part of the accumulator's dequantisation is d_act[0] when d_act is non-null (device), else the host
 // value ab_scale; d_wrow (device, [N], optional) multiplies per-output-channel weight scales onto it; d_out (device, 1
 // float: scale of the fp8 output) overrides out_inv_scale.
 int launch_gemm_fp8(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K, int epi,
                     const float *lam, const float *R, float *Y2, float ab_scale, float out_inv_scale, const float *d_act,
                     const float *d_wrow, const float *d_out, hipStream_t stream);
-int launch_quant_rows_fp8(const float *W, void *dst, float *scales, int N, int K, hipStream_t stream);
+int launch_quant_rows_fp8(const float *W, void *dst, float *scales, int N, int K, hipStream_t stream, float mul = 1.0f);
 int launch_quant_fp8(const float *src, void *dst, size_t n, float inv_scale, const float *d_scale, hipStream_t stream);
 int launch_amax_f32(const float *src, size_t n, float *out, bool accumulate, hipStream_t stream);
 int launch_amax_to_scale(float *p, int n, hipStream_t stream);   // p[i] = max(p[i], tiny) / 448
@@ -214,7 +214,7 @@ int launch_layernorm_fp8out(const float *X, const float *g, const float *b, void
                             const float *qscale, hipStream_t stream);
 int launch_attention_bf16_fp8out(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ldq,
                                  int ldk, int ldv, int ldo, float scale, const float *qscale, hipStream_t stream);
-int launch_pack_qkv_bias(const float *bq, const float *bv, float *dst, int C, hipStream_t stream);
+int launch_pack_qkv_bias(const float *bq, const float *bv, float *dst, int C, hipStream_t stream, float qmul = 1.0f);
 
 // ---- train step (train_ops.hip, attention_bwd_bf16.hip, api_train.hip) ----------------------------------------------------
 // second stage of the column reductions / split-K slab sums: out[j][n] = sum_{p < P[j]} part[j][p * stride[j] + n]

@@ -17,12 +17,13 @@ __global__ void __launch_bounds__(256) cls_rows(const float *__restrict__ cls, c
 }
 
 // dst[0:C] = bq ; dst[C:2C] = 0 (key projection has no bias, TF:306) ; dst[2C:3C] = bv
+// (qmul: pack-time factor on the query bias, see ldit_pack_weights)
 __global__ void __launch_bounds__(256) qkv_bias(const float *__restrict__ bq, const float *__restrict__ bv,
-                                                float *__restrict__ dst, int C)
+                                                float *__restrict__ dst, int C, float qmul)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= 3 * C) return;
-    dst[i] = i < C ? bq[i] : (i < 2 * C ? 0.0f : bv[i - 2 * C]);
+    dst[i] = i < C ? bq[i] * qmul : (i < 2 * C ? 0.0f : bv[i - 2 * C]);
 }
 
 // One thread per 4 consecutive channels of one output pixel: the token-major tap is read as float4 along C
@@ -234,9 +235,9 @@ int launch_cls_rows(const float *cls, const float *pos, float *out, int B, int t
     return LDIT_OK;
 }
 
-int launch_pack_qkv_bias(const float *bq, const float *bv, float *dst, int C, hipStream_t stream)
+int launch_pack_qkv_bias(const float *bq, const float *bv, float *dst, int C, hipStream_t stream, float qmul)
 {
-    hipLaunchKernelGGL(qkv_bias, dim3((3 * C + 255) / 256), dim3(256), 0, stream, bq, bv, dst, C);
+    hipLaunchKernelGGL(qkv_bias, dim3((3 * C + 255) / 256), dim3(256), 0, stream, bq, bv, dst, C, qmul);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }

@@ -280,7 +280,8 @@ def linear_fp8(x: torch.Tensor, weight: torch.Tensor, ab_scale: float, bias: Opt
     return out
 
 
-def attention_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None) -> torch.Tensor:
+def attention_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: Optional[float] = None,
+                   prescaled: bool = False) -> torch.Tensor:
     """bf16 fused attention; ``q, k, v``: bf16 [B, N, H*D] token-major (column slices of a fused tensor are fine)."""
     lib = _lib.load()
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
@@ -289,8 +290,9 @@ def attention_bf16(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int
     B, N, HD = q.shape
     D = HD // heads
     o = torch.empty((B, N, HD), device=q.device, dtype=torch.bfloat16)
+    # prescaled: q already carries scale * log2(e) (the packed inference path); the library is told so with scale = 0
     _launch(_device(q, k, v), lib.ldit_attention_bf16, _ptr(q), _ptr(k), _ptr(v), _ptr(o), B, N, heads, D, q.stride(1), k.stride(1),
-                                       v.stride(1), HD, float(D ** -0.5 if scale is None else scale))
+                                       v.stride(1), HD, 0.0 if prescaled else float(D ** -0.5 if scale is None else scale))
     return o
 
 

@@ -14,16 +14,20 @@ lib = C.CDLL(os.path.join(ROOT, "layoutdit_amd", "csrc", "build", "libldit_hip_d
 vp, i64 = C.c_void_p, C.c_int64
 lib.ldit_attention_bf16.argtypes = [vp] * 4 + [i64] * 8 + [C.c_float, vp]
 lib.ldit_dbg_set_attn_stamps.argtypes = [vp]
+PRE = os.environ.get("PRE", "0") == "1"      # PRE=1: q carries scale * log2(e), the kernel is called with scale = 0
 for B, N, H in ((16, 1025, 16), (64, 197, 12)):
     Cc = 64 * H
-    qkv = torch.randn(B, N, 3 * Cc, device="cuda").to(torch.bfloat16)
+    qkv = (0.35 * torch.randn(B, N, 3 * Cc, device="cuda"))
+    if PRE:
+        qkv[..., :Cc] *= 0.125 * 1.4426950408889634
+    qkv = qkv.to(torch.bfloat16)
     o = torch.empty(B, N, Cc, device="cuda", dtype=torch.bfloat16)
     nwg = B * H * ((((N + 31) // 32) + 3) // 4)
     st = torch.zeros(nwg * 6, dtype=torch.int64, device="cuda")
     assert lib.ldit_dbg_set_attn_stamps(st.data_ptr()) == 0
     for _ in range(20):
         rc = lib.ldit_attention_bf16(qkv.data_ptr(), qkv.data_ptr() + 2 * Cc, qkv.data_ptr() + 4 * Cc, o.data_ptr(), B, N, H, 64,
-                                     3 * Cc, 3 * Cc, 3 * Cc, Cc, 0.125, None)
+                                     3 * Cc, 3 * Cc, 3 * Cc, Cc, 0.0 if PRE else 0.125, None)
         assert rc == 0
     torch.cuda.synchronize()
     s = st.cpu().numpy().reshape(nwg, 6)

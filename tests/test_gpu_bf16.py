@@ -86,6 +86,36 @@ def test_attention_bf16(B, N, H):
     assert np.isfinite(o).all()
 
 
+@pytest.mark.parametrize("B,N,H", [(1, 197, 3), (2, 33, 2), (1, 64, 1), (1, 257, 2), (1, 1025, 3), (2, 128, 2)])
+def test_attention_bf16_prescaled_queries(B, N, H):
+    """The packed inference path hands the kernel q' = (scale log2 e) q (folded into W_q at pack time) and scale = 0: scores are
+    exp2-domain exponents, the running maximum is subtracted by an extra MFMA step (two bf16 terms).  Against the float64
+    softmax of the ROUNDED q' (what the kernel sees), every regime of the maximum logic forced by the data (rule 26):
+      * a dominant key in the LAST chunk (the maximum jumps by far more than the deferred-rescale threshold 2^8),
+      * all scores of the FIRST chunk very negative (the first chunk re-bases on its own maximum; nothing may underflow to l = 0),
+      * scores that creep up chunk by chunk (many small growths below the threshold, then one above)."""
+    D = 64
+    c = D ** -0.5 * np.log2(np.e)
+    q, k, v = (_rand(120 + i, B, N, H * D) for i in range(3))
+    k[:, N - 3] *= 5.0                                         # dominant key in the last chunk
+    if N > 64:
+        k[:, :64] = -np.abs(k[:, :64]) * 1.5                   # first chunk: strongly negative against a positive query block
+        q[:, ::2] = np.abs(q[:, ::2]) * 1.2
+    k *= np.linspace(0.6, 1.6, N, dtype=np.float32)[None, :, None]     # creeping growth
+    qp = _bf16_round((q * c).astype(np.float32))
+    k, v = _bf16_round(k), _bf16_round(v)
+    dev = [torch.from_numpy(a).to(DEV).to(torch.bfloat16) for a in (qp, k, v)]
+    o = ops.attention_bf16(*dev, heads=H, prescaled=True).float().cpu().numpy()
+    # float64 reference: softmax of the natural-log scores ln(2) * (q' . k)
+    qh, kh, vh = (torch.from_numpy(a).double().view(B, N, H, D).transpose(1, 2) for a in (qp, k, v))
+    ref = (torch.softmax(np.log(2.0) * (qh @ kh.transpose(-1, -2)), -1) @ vh).transpose(1, 2).reshape(B, N, H * D).numpy()
+    assert np.isfinite(o).all()
+    assert rel_l2(o, ref) < 6e-3
+    # and the plain entry (scale applied in the kernel) agrees with it on the unscaled queries' own rounding
+    o2 = ops.attention_bf16(torch.from_numpy(_bf16_round(q)).to(DEV).to(torch.bfloat16), dev[1], dev[2], heads=H).float().cpu().numpy()
+    assert rel_l2(o2, o) < 1.5e-2
+
+
 def test_attention_bf16_on_fused_views_and_large_logits():
     B, N, H, D = 2, 300, 2, 64
     qkv = _bf16_round(_rand(30, B, N, 3 * H * D))
