@@ -208,6 +208,13 @@ int ldit_attention_bf16(const void *Q, const void *K, const void *V, void *O, in
 /* dst[i] = bf16(src[i]) (round to nearest even), n elements. */
 int ldit_cast_f32_bf16(const void *src, void *dst, int64_t n, ldit_stream stream);
 
+/* ldit_embed_f32's arithmetic on bf16 MFMA operands - the patch embedding of the bf16 / fp8 builds and of the train step
+ * (TF:81-90, TF:153-176): x fp32 NCHW is rounded to a bf16 im2col matrix [B*P, in_ch*p*p] in `scratch` (that many bf16, 16-byte
+ * aligned; one HBM-bound pass), multiplied with patch_w_bf16 [C, in_ch*p*p] (fp32 accumulation), bias and position rows added in
+ * fp32, written to token rows 1.. of out fp32 [B, 1+P, C]; row 0 = cls + pos[0].  (in_ch*p*p) % 64 == 0, C % 4 == 0. */
+int ldit_embed_bf16(const void *x, const void *patch_w_bf16, const void *patch_b, const void *cls, const void *pos, void *out,
+                    void *scratch, int64_t B, int64_t in_ch, int64_t img_h, int64_t img_w, int64_t p, int64_t C, ldit_stream stream);
+
 /* ---- fp8 (OCP e4m3) building blocks of the fp8 build (BASELINE.json configs[4]) -----------------------------------------
  * Symmetric scaling: activations per tensor (T ~= scale_T * q, scale_T = amax(T) / 448), weights per output channel
  * (W[n,:] ~= w_scales[n] * q[n,:]).

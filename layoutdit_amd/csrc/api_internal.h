@@ -47,6 +47,7 @@ inline int geometry(const ldit_cfg *cfg, Geo &g)
 struct PackedLayer { size_t ln1_w, ln1_b, wqkv, bqkv, wo, bo, lam1, ln2_w, ln2_b, w1, b1, w2, b2, lam2, scales, sw_qkv, sw_o, sw_1, sw_2; };
 struct PackedMap {
     size_t patch_w, patch_b, cls, pos, total;
+    size_t patch_w16;   // bf16 / fp8 builds: bf16 copy of the patch projection (the patch embedding runs on the bf16 GEMM there)
     std::vector<PackedLayer> layer;
 };
 
@@ -60,6 +61,7 @@ inline PackedMap packed_map(const Geo &g, int dtype)
     m.patch_b = take(g.C, 4);
     m.cls = take(g.C, 4);
     m.pos = take((size_t)g.T * g.C, 4);
+    m.patch_w16 = dtype != LDIT_F32 ? take((size_t)g.C * g.Kp, 2) : 0;
     m.layer.resize(g.L);
     for (int l = 0; l < g.L; ++l) {
         PackedLayer &pl = m.layer[l];
@@ -91,7 +93,9 @@ inline Workspace workspace_map(const Geo &g, int batch, int dtype)
     auto take = [&](size_t bytes) { size_t at = o; o += up(bytes, 256); return at; };
     w.h = take(M * g.C * 4);       // residual stream (always fp32)
     w.y = take(M * g.C * act);     // LayerNorm output, then attention output
-    w.big = take(M * wide * act);  // fused q|k|v, later the MLP hidden (never live together)
+    size_t big = M * wide * act;   // fused q|k|v, later the MLP hidden (never live together)
+    if (dtype != LDIT_F32 && big < (size_t)batch * g.P * g.Kp * 2) big = (size_t)batch * g.P * g.Kp * 2;   // before layer 0: bf16 im2col of the batch
+    w.big = take(big);
     w.total = o;
     return w;
 }

@@ -63,9 +63,16 @@ __device__ __forceinline__ void store_rows_via_lds(const f32x16 (&acc)[TM][TN], 
             for (int r = 0; r < 8; ++r) {
                 const int row = 4 * r + rrow;
                 f32x4 v = *reinterpret_cast<const f32x4 *>(buf + row * EPI_ROW_BYTES + rq * 16);
-                const unsigned o = (unsigned)(mw + 32 * i + row) * (unsigned)ldy + n;
+                unsigned o = (unsigned)(mw + 32 * i + row) * (unsigned)ldy + n;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], abq[e], biasq[e]);
+                if (EPI == EPI_EMBED) {
+                    const unsigned m = (unsigned)(mw + 32 * i + row), img = m / (unsigned)x.patches, pi = m - img * (unsigned)x.patches;
+                    const f32x4 pq = *reinterpret_cast<const f32x4 *>(x.pos + ((pi + 1u) * (unsigned)ldy + n));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += pq[e];
+                    o = (m + img + 1u) * (unsigned)ldy + n;
+                }
                 if (EPI == EPI_SCALE_RESID && x.Ypre) {
                     const epi_bf16x4 pre = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                     *reinterpret_cast<epi_bf16x4 *>(static_cast<__bf16 *>(x.Ypre) + o) = pre;

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
 #ifdef LDIT_BF16_NO_SPLIT            // A/B build only (scripts/ab_bf16_split.sh): every wave issues its own pieces, as in round 1
     constexpr bool SPLIT = false;
 #else
-    constexpr bool SPLIT = NWAVES == 8 && !(TM == 5 && (EPI == EPI_SCALE_RESID || EPI == EPI_F32));
+    constexpr bool SPLIT = NWAVES == 8 && !(TM == 5 && (EPI == EPI_SCALE_RESID || EPI == EPI_F32 || EPI == EPI_EMBED));
 #endif
     constexpr int LW = SPLIT ? NWAVES / 2 : NWAVES;      // waves that issue
     constexpr int NLW = ROWS / (8 * LW);                 // pieces per issuing wave and k-tile
@@ -345,8 +345,8 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
     // Measured and dropped (profiles/README.md): a four-stage and a five-stage counted-vmcnt ring, a 256 x 128 ring at two
     // workgroups per CU, a barrier-phased ping-pong of the two waves per SIMD, a v_mfma_f32_16x16x32_bf16 build and a
     // four-wave 256 x 256 tile - none beat this kernel on any shape; the 256 x 128 tile stays selectable for experiments.
-    // (EPI_EMBED unused here; EPI_F32 priced like the residual epilogue, EPI_GELU_BWD like the GELU one)
-    const double a256[6] = {19.0, 18.5, 25.0, 0.0, 25.0, 18.5}, r128[6] = {5.2, 5.0, 7.7, 0.0, 7.7, 5.0};
+    // (EPI_EMBED and EPI_F32 priced like the residual epilogue, EPI_GELU_BWD like the GELU one)
+    const double a256[6] = {19.0, 18.5, 25.0, 25.0, 25.0, 18.5}, r128[6] = {5.2, 5.0, 7.7, 7.7, 7.7, 5.0};
     const long sp = a.x.splits;
     const long t256 = sp * ((a.M + 255) / 256) * ((a.N + 255) / 256), t128 = sp * ((a.M + 127) / 128) * ((a.N + 127) / 128);
     const double Ks = (double)a.K / (double)sp;            // k-depth one block walks
@@ -403,7 +403,8 @@ int launch_gemm_bf16_ex(const void *A, int lda, const void *W, const float *bias
 {
     const int rem = M % 256;
     const long nbn = (N + 255) / 256, full = ((long)M / 256 + 1) * nbn, mainp = ((long)M / 256) * nbn;
-    if (rem != 0 && rem <= 64 && M > 256 && x.splits == 1 && (full + 255) / 256 > (mainp + 255) / 256) {   // peel only when it saves a round
+    // (the patch-embedding epilogue maps rows by their GLOBAL index: never peeled)
+    if (rem != 0 && rem <= 64 && M > 256 && x.splits == 1 && epi != EPI_EMBED && (full + 255) / 256 > (mainp + 255) / 256) {   // peel only when it saves a round
         const int main_rows = M - rem;
         const size_t out_elt = (epi == EPI_SCALE_RESID || epi == EPI_F32) ? 4 : 2;
         int rc = launch_gemm_bf16_one(A, lda, W, bias, Y, ldy, main_rows, N, K, epi, lam, R, Y2, x, stream);
@@ -449,6 +450,10 @@ static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const flo
             if (!lam || !R) return fail(LDIT_EINVAL, "gemm_bf16: scale+residual epilogue needs lam and R");
             return launch_h_tiled<EPI_SCALE_RESID>(a, stream);
         case EPI_F32: return launch_h_tiled<EPI_F32>(a, stream);
+        case EPI_EMBED:
+            if (!x.pos || x.patches <= 0 || M % x.patches || !aligned16(x.pos) || (ldy & 3))
+                return fail(LDIT_EINVAL, "gemm_bf16: patch-embedding epilogue needs pos, patches | M and 16-byte rows");
+            return launch_h_tiled<EPI_EMBED>(a, stream);
         case EPI_GELU_BWD:
             if (!x.aux || (x.ldaux & 3) || (reinterpret_cast<uintptr_t>(x.aux) & 7u)) return fail(LDIT_EINVAL, "gemm_bf16: GELU-backward epilogue needs an aligned pre-activation operand");
             return launch_h_tiled<EPI_GELU_BWD>(a, stream);

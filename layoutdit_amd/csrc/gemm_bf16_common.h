@@ -35,7 +35,7 @@ struct GemmArgsH {
     GemmExtra x;         // train-step operands (Ypre, rowscale, aux, split-K); defaults = inference
 };
 
-template <int EPI> constexpr bool f32_out() { return EPI == EPI_SCALE_RESID || EPI == EPI_F32; }
+template <int EPI> constexpr bool f32_out() { return EPI == EPI_SCALE_RESID || EPI == EPI_F32 || EPI == EPI_EMBED; }
 
 // MODE 0: tile inside the matrix, 16-B / 8-B accesses unchecked; MODE 1: columns inside, rows past M skipped (the ragged
 // last row tile keeps its vector accesses - a lane owns a row, so the element-wise path does not coalesce and cost ~20 us);
@@ -75,13 +75,21 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
                 asm volatile("" ::: "memory");
             }
             const float rs = (EPI == EPI_SCALE_RESID && p.x.rowscale) ? p.x.rowscale[m] : 1.0f;
+            const unsigned img = EPI == EPI_EMBED ? (unsigned)m / (unsigned)p.x.patches : 0u;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = nw + j * 32 + 8 * g + 4 * h;
-                const unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
+                unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bias[g][e];
+                if (EPI == EPI_EMBED) {
+                    // token row of patch row m (one CLS slot in front of every image) + its position row, as the slab epilogue
+                    const float *pq = p.x.pos + (((unsigned)m - img * (unsigned)p.x.patches + 1u) * (unsigned)p.ldy + (unsigned)n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (MODE != 2 || n + e < p.N) ? pq[e] : 0.0f;
+                    o = ((unsigned)m + img + 1u) * (unsigned)p.ldy + (unsigned)n;
+                }
                 bool gelu_done = false;
                 if ((EPI == EPI_BIAS_GELU || EPI == EPI_SCALE_RESID) && p.x.Ypre) {
                     // saved for the backward: the pre-LayerScale value, or the GELU derivative at the pre-activation (train forward:

@@ -140,6 +140,10 @@ struct GemmExtra {
     int ldaux = 0;
     int splits = 1;                    // EPI_F32: K split into `splits` slabs, slab s at (float*)Y + s * M * ldy
     const void *zeros = nullptr;       // gemm_bf16_tr.hip: >= 128 bytes of device zeros (source of reduction rows past the end)
+    // EPI_EMBED (bf16 GEMM on the bf16 im2col of the batch, launch_patches_rows): row m = (image b, patch i) lands in token row
+    // b * (patches + 1) + 1 + i of the fp32 output with pos[1 + i] added (TF:153-176; the CLS rows are launch_cls_rows')
+    const float *pos = nullptr;        // fp32 [patches + 1, N], row stride ldy
+    int patches = 0;
 };
 
 struct GemmArgs {

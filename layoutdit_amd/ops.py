@@ -108,6 +108,23 @@ def embed(x: torch.Tensor, patch_w: torch.Tensor, patch_b: torch.Tensor, cls: to
     return out
 
 
+def embed_bf16(x: torch.Tensor, patch_w_bf16: torch.Tensor, patch_b: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor,
+               patch: int) -> torch.Tensor:
+    """The patch embedding of the bf16 / fp8 builds and of the train step: bf16 im2col of the batch + bf16 MFMA GEMM, fp32 out."""
+    lib = _lib.load()
+    x, patch_b, cls, pos = _req(x, "x"), _req(patch_b, "patch_b"), _req(cls, "cls"), _req(pos, "pos")
+    if patch_w_bf16.dtype != torch.bfloat16 or not patch_w_bf16.is_contiguous():
+        raise ValueError("patch_w_bf16 must be a contiguous bfloat16 tensor")
+    B, in_ch, H, W = x.shape
+    Cc = patch_w_bf16.shape[0]
+    P = (H // patch) * (W // patch)
+    out = torch.empty((B, P + 1, Cc), device=x.device, dtype=torch.float32)
+    scratch = torch.empty((B * P, in_ch * patch * patch), device=x.device, dtype=torch.bfloat16)
+    _launch(_device(x, patch_w_bf16, patch_b, cls, pos), lib.ldit_embed_bf16, _ptr(x), _ptr(patch_w_bf16), _ptr(patch_b), _ptr(cls),
+            _ptr(pos), _ptr(out), _ptr(scratch), B, in_ch, H, W, patch, Cc)
+    return out
+
+
 def tap_to_map(tap: torch.Tensor, gh: int, gw: int, scale: float) -> torch.Tensor:
     lib = _lib.load()
     tap = _req(tap, "tap")

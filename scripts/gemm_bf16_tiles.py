@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from layoutdit_amd import _lib, ops  # noqa: E402
 FP8 = os.environ.get("DT", "bf16") == "fp8"
 ENV = "LDIT_GEMM_FP8_TILE" if FP8 else "LDIT_GEMM_BF16_TILE"
-TILES = ("2", "0", "3", "4", "auto") if FP8 else ("2", "3", "4", "5", "auto")
+TILES = tuple(os.environ.get("TILES", "2,0,3,4,5,6,auto" if FP8 else "2,3,4,5,6,7,auto").split(","))
 DT = torch.float8_e4m3fn if FP8 else torch.bfloat16
 def run(x, w, b, **kw):
     return ops.linear_fp8(x, w, 0.01, b, **kw) if FP8 else ops.linear_bf16(x, w, b, **kw)
@@ -18,7 +18,7 @@ def shapes(M, C):
     return [("qkv", M, 3 * C, C, _lib.EPI_BIAS), ("o_proj", M, C, C, _lib.EPI_SCALE_RESID), ("fc1", M, F, C, _lib.EPI_BIAS_GELU),
             ("fc2", M, C, F, _lib.EPI_SCALE_RESID)]
 
-for M, C in ((64 * 197, 768), (32 * 197, 768), (16 * 1025, 1024)):
+for M, C in ((64 * 197, 768), (32 * 197, 768), (16 * 1024, 1024)):
     for name, m, n, k, epi in shapes(M, C):
         x = torch.randn(m, k, device="cuda").to(DT); w = (torch.randn(n, k, device="cuda") * (1.0 if FP8 else 0.05)).to(DT)
         b = torch.randn(n, device="cuda"); lam = torch.rand(n, device="cuda"); r = torch.randn(m, n, device="cuda")

@@ -152,9 +152,10 @@ def test_low_precision_builds_keep_the_checkpoint_surface_and_size_their_buffers
     lc = _cfg(cfg)
     f32 = lib.ldit_packed_bytes(C.byref(lc))
     lc.dtype = _lib.DTYPE_BF16
-    assert lib.ldit_packed_bytes(C.byref(lc)) == f32 - 2 * mats
+    pw16 = 2 * 768 * 768                             # bf16 copy of the patch projection: the low-precision builds embed on the bf16 GEMM
+    assert lib.ldit_packed_bytes(C.byref(lc)) == f32 - 2 * mats + pw16
     lc.dtype = _lib.DTYPE_FP8
-    assert lib.ldit_packed_bytes(C.byref(lc)) == f32 - 3 * mats + 12 * (32 + 4 * (3 * 768 + 768 + 3072 + 768))   # + scales
+    assert lib.ldit_packed_bytes(C.byref(lc)) == f32 - 3 * mats + pw16 + 12 * (32 + 4 * (3 * 768 + 768 + 3072 + 768))   # + scales
     lt = _cfg(cfgs.vit_tiny())                       # hidden 192: not a multiple of the fp8 k-tile
     lt.dtype = _lib.DTYPE_FP8
     assert lib.ldit_packed_bytes(C.byref(lt)) == 0 and "multiples of 128" in lib.ldit_last_error().decode()

@@ -247,6 +247,33 @@ def test_embed(B, H, W, C):
     assert max_rel(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 64), (3, 224, 224, 192), (1, 96, 160, 128), (5, 224, 224, 768), (2, 512, 512, 256)])
+def test_embed_bf16_is_the_oracle_embedding_of_the_bf16_rounded_operands(B, H, W, C):
+    """The patch embedding of the bf16 / fp8 builds and of the train step (ldit_embed_bf16): bf16 im2col + bf16 MFMA GEMM with the
+    row-remapping epilogue.  Products of bf16 values are exact in fp32, so against the oracle (TF:81-90, TF:153-176) fed the SAME
+    bf16-rounded pixels and projection only the accumulation order differs: 1e-5; against the unrounded operands: the bf16 gate.
+    Geometries cover whole 256-row tiles through the slab epilogue (5 x 196, 2 x 1024 rows), ragged last tiles and sub-tile
+    problems (direct epilogue), and N below one 256-column tile."""
+    x = synth.synth_images(B, H, W, seed=5, kind="uniform")
+    pw, pb = _rand(40, C, 3, 16, 16, scale=0.02), _rand(41, C, scale=0.02)
+    T = (H // 16) * (W // 16) + 1
+    cls, pos = _rand(42, C, scale=0.02), _rand(43, T, C, scale=0.02)
+    pw16 = _dev(pw).to(torch.bfloat16).contiguous()
+    out = ops.embed_bf16(_dev(x), pw16.reshape(C, -1), _dev(pb), _dev(cls), _dev(pos), 16).cpu().numpy()
+    xr = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+    pwr = pw16.to(torch.float32).cpu().numpy()
+    ref = np.empty((B, T, C), np.float32)
+    oracle.lib().oracle_embed(xr.ctypes.data, pwr.ctypes.data, pb.ctypes.data, cls.ctypes.data, pos.ctypes.data, B, 3, H, W, 16, C,
+                              ref.ctypes.data)
+    assert rel_l2(out, ref) < 1e-5 and max_rel(out, ref) < 1e-5
+    full = np.empty((B, T, C), np.float32)
+    oracle.lib().oracle_embed(x.ctypes.data, pw.ctypes.data, pb.ctypes.data, cls.ctypes.data, pos.ctypes.data, B, 3, H, W, 16, C,
+                              full.ctypes.data)
+    assert rel_l2(out, full) < 2e-2
+    again = ops.embed_bf16(_dev(x), pw16.reshape(C, -1), _dev(pb), _dev(cls), _dev(pos), 16).cpu().numpy()
+    assert np.array_equal(out, again)
+
+
 def test_tap_to_map_golden(golden_dir):
     g5 = np.load(os.path.join(golden_dir, "g5_maps.npz"))
     g0 = np.load(os.path.join(golden_dir, "g0_micro.npz"))
