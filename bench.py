@@ -10,6 +10,8 @@
     2  ViT-B/16 224x224 bs=64/GPU bf16 train step: forward + backward + gradient all-reduce (RCCL, N > 1) + fused AdamW
     3  ViT-L/16 512x512 bs=16/GPU bf16 forward (N = 1025 tokens)
     4  ViT-B/16 224x224 bs=32/GPU fp8 forward (bs=256 over 8 GPUs)
+    5  config 1 on the split-fp32 build "f32x3" (every GEMM = three bf16-plane products on the bf16 MFMA, fp32 everything else)
+    6  config 1 on "f32x6" (six plane products: the error of fp32 arithmetic)
 (`--model/--size/--batch/--dtype` still override single fields for experiments.)
 
 With `--gpus N > 1` and no WORLD_SIZE in the environment the script launches itself: the parent process (which never
@@ -24,6 +26,9 @@ barrier + synchronize brackets (max over ranks); rank 0 prints ONE JSON line.  E
                  in a second K-step pass with events on the launch stream, against the dense MFMA peak of the dtype;
                  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_traffic.json,
                  labelled with the commit they were collected on) or null
+  split_fp32   - (N = 1, config 1 only) the SAME workload on the two split-fp32 builds, measured in the same process right after the
+                 headline: images/sec, ms per step, and the relative-L2 distance of every tap from the headline (fp32 MFMA) build's
+                 taps.  Reported beside the headline, never as `value`: the headline stays the exact-fp32 MFMA path
   cpu_baseline - (N = 1, config 1 only) the same forward on the host cores: the torch-ops restatement in oracle/ (value)
                  and the plain-C OpenMP restatement beside it, best + median of 5, CPU model and core count
 """
@@ -41,12 +46,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0}   # dense MFMA peaks, MI355X_MICROARCH.md (never the 2:1-sparse figures)
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "fp8": 5000.0,   # dense MFMA peaks, MI355X_MICROARCH.md (never the 2:1-sparse figures)
+               "f32x3": 2500.0 / 3, "f32x6": 2500.0 / 6}        # split-fp32 builds: 3 / 6 bf16 MFMA plane products per fp32 product
 CONFIGS = {
     1: dict(model="base", size=224, batch=64, dtype="f32", mode="forward"),
     2: dict(model="base", size=224, batch=64, dtype="bf16", mode="train"),
     3: dict(model="large", size=512, batch=16, dtype="bf16", mode="forward"),
     4: dict(model="base", size=224, batch=32, dtype="fp8", mode="forward"),
+    5: dict(model="base", size=224, batch=64, dtype="f32x3", mode="forward"),
+    6: dict(model="base", size=224, batch=64, dtype="f32x6", mode="forward"),
 }
 
 
@@ -58,11 +66,12 @@ def parse_args(argv=None):
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[i]")
     ap.add_argument("--model", default=None, choices=["micro", "tiny", "base", "large"])
     ap.add_argument("--size", type=int, default=None)
-    ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "fp8"])
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "fp8", "f32x3", "f32x6"])
     ap.add_argument("--batch", type=int, default=None, help="images per GPU")
     ap.add_argument("--mode", default=None, choices=["forward", "train"])
     ap.add_argument("--cpu-sample", type=int, default=64, help="images timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-roofline-pass", action="store_true")
+    ap.add_argument("--no-split-fp32", action="store_true", help="skip the split-fp32 builds beside the headline line")
     args = ap.parse_args(argv)
     for k, v in CONFIGS[args.config].items():
         if getattr(args, k) is None:
@@ -221,6 +230,38 @@ def cpu_baseline(cfg, weights, x_np, sample: int):
                       f"median {med:.2f} s"}
 
 
+def split_fp32_lines(cfg, weights, x, ref_out, steps, warmup, dev):
+    """Config 1 on the split-fp32 builds (include/ldit.h LDIT_F32X3 / LDIT_F32X6), timed with HIP events over `steps` forwards."""
+    import torch
+    from layoutdit_amd.modeling import DiTEncoder
+    res = {}
+    for dt, products in (("f32x6", 6), ("f32x3", 3)):
+        m = DiTEncoder(cfg, compute_dtype=dt).load_numpy(weights).to(dev).eval()
+        with torch.no_grad():
+            for _ in range(max(warmup, 1)):
+                out = m(x)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                out = m(x)
+            e1.record()
+            torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / steps
+        errs = [float((out.hidden_states[t] - ref_out.hidden_states[t]).norm() / ref_out.hidden_states[t].norm()) for t in cfg.taps]
+        tf = cfg.flops_per_image(x.shape[2], x.shape[3]) * x.shape[0] / (ms * 1e-3) / 1e12
+        res[dt] = {"value": round(x.shape[0] / (ms * 1e-3), 2), "unit": "images/sec", "ms_per_step": round(ms, 4),
+                   "plane_products_per_fp32_product": products, "model_tflops_fp32_equivalent": round(tf, 2),
+                   "bf16_mfma_roofline_frac": round(tf * products / 2500.0, 4),
+                   "rel_l2_vs_headline_taps": [float(f"{e:.3e}") for e in errs]}
+        del m
+    res["note"] = ("same workload, same process; GEMM operands held as 3 (2) bf16 planes of the fp32 value, products on "
+                   "v_mfma_f32_32x32x16_bf16 with fp32 accumulation; LayerNorm / attention / erf-GELU / residual fp32 as in the headline. "
+                   "Error vs the float64 oracle (tests/test_gpu_split_fp32.py, ViT-B): f32x6 5.3-5.7e-7, headline fp32 MFMA build 7.2-9.3e-7, "
+                   "f32x3 3.0-4.6e-6")
+    return res
+
+
 def percentiles(ms):
     import numpy as np
     a = np.sort(np.asarray(ms, dtype=np.float64))
@@ -343,11 +384,14 @@ def run_rank(args) -> None:
                                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                                 "traffic_source": source,
                                 "kernel": "fp32 MFMA GEMM family (patch-embed, qkv, o_proj, fc1, fc2)" if args.dtype == "f32"
-                                else f"{args.dtype} MFMA GEMM family (qkv, o_proj, fc1, fc2"
+                                else f"bf16 MFMA GEMM family on split fp32 operands ({args.dtype}: peak = 2.5 PF / plane products per fp32 "
+                                     f"product; patch-embed stays on the fp32 MFMA)" if args.dtype.startswith("f32x") else f"{args.dtype} MFMA GEMM family (qkv, o_proj, fc1, fc2"
                                      + (" + their dgrad / wgrad" if train else "") + "; patch-embed stays fp32)",
                                 "launches": n, "avg_launch_ms": round(timing["gemm_ms"] / n, 5),
                                 "flops_per_launch": gemm_flops // n}
             line["kernel_ms_per_step"] = {k[:-3]: round(v / args.steps, 4) for k, v in timing.items() if k.endswith("_ms")}
+        if r.world == 1 and headline and not args.no_split_fp32:
+            line["split_fp32"] = split_fp32_lines(cfg, weights, x, out, args.steps, args.warmup, dev)
         if r.world == 1 and args.cpu_sample > 0 and headline:
             line["cpu_baseline"] = cpu_baseline(cfg, weights, x_np, min(args.cpu_sample, args.batch))
         print(json.dumps(line), flush=True)

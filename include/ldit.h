@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LDIT_ABI_VERSION 3
+#define LDIT_ABI_VERSION 4
 #define LDIT_MAX_TAPS 8
 
 enum ldit_status {
@@ -42,11 +42,18 @@ enum ldit_status {
 enum ldit_dtype {
     LDIT_F32 = 0,  /* everything fp32 (exact-fp32 MFMA) */
     LDIT_BF16 = 1, /* GEMM / attention operands bf16, fp32 accumulation, residual stream / LayerNorm / softmax fp32; taps fp32 */
-    LDIT_FP8 = 3   /* BASELINE.json configs[4]: the four GEMMs of a layer on fp8 e4m3 (OCP) operands with per-tensor scales,
+    LDIT_FP8 = 3,  /* BASELINE.json configs[4]: the four GEMMs of a layer on fp8 e4m3 (OCP) operands with per-tensor scales,
                       fp32 accumulation; attention on bf16 q|k|v; residual stream / LayerNorm / softmax fp32; taps fp32.
                       Weight scales (one per output channel) are measured by ldit_pack_weights; the four per-tensor
                       activation scales per layer come from
                       ldit_set_fp8_act_scales (calibration is the caller's job) */
+    LDIT_F32X3 = 4, /* fp32 forward with every GEMM operand held as TWO bf16 planes x ~= p0 + p1 (p0 = bf16(x), p1 = bf16(x - p0):
+                      16 significant bits) and every product computed as p1.q0 + p0.q1 + p0.q0 on the bf16 MFMA (16x the fp32
+                      matrix rate) with fp32 accumulation - "bf16x3".  Residual stream, LayerNorm, attention (the fp32 kernel), erf-GELU,
+                      biases and taps are fp32 exactly as in LDIT_F32.  Whole-path error vs float64: 3 - 5e-6 relative L2 (LDIT_F32:
+                      5e-7), i.e. inside the fp32 build's own parity gates (2e-5) and 200x inside the north-star 1e-3. */
+    LDIT_F32X6 = 5  /* the same with THREE planes (24 significant bits) and the six plane products down to 2^-24: fp32-grade error
+                      (5e-7 vs float64, that of the fp32 MFMA path and of ATen's CPU fp32 GEMMs) at 6 bf16 MFMAs per product */
 };
 
 /* order of the per-layer activation scales handed to ldit_set_fp8_act_scales (scale = amax / 448) */
@@ -207,6 +214,20 @@ int ldit_attention_bf16(const void *Q, const void *K, const void *V, void *O, in
 
 /* dst[i] = bf16(src[i]) (round to nearest even), n elements. */
 int ldit_cast_f32_bf16(const void *src, void *dst, int64_t n, ldit_stream stream);
+
+/* ---- split-fp32 building blocks (LDIT_F32X3 / LDIT_F32X6) ------------------------------------------------------------------
+ * ldit_split_f32_planes: dst bf16 [rows, planes * cols] = the bf16 planes p0 | p1 (| p2) of src fp32 [rows, cols] (row stride lds),
+ *   p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1); planes = 2 or 3; cols % 4 == 0.
+ * ldit_layernorm_f32_planes: ldit_layernorm_f32 with the result written as such planes, Y bf16 [rows, planes * C].
+ * ldit_linear_planes: Y = epilogue(X . W^T) for fp32 X [M,K] and W [N,K] given as planes Xp [M, planes * K] (row stride lda), Wp [N,
+ *   planes * K]: the sum of 3 (planes = 2: x1 w0 + x0 w1 + x0 w0) or 6 (planes = 3: + x2 w0 + x1 w1 + x0 w2) plane products on
+ *   v_mfma_f32_32x32x16_bf16, smallest first, ONE fp32 accumulation chain per output element.  K % 64 == 0.  LDIT_EPI_BIAS and
+ *   LDIT_EPI_SCALE_RESID write fp32 Y (row stride ldy); LDIT_EPI_BIAS_GELU (exact erf-GELU) writes Y as planes, bf16 [M, planes * N]. */
+int ldit_split_f32_planes(const void *src, int64_t lds, void *dst, int64_t rows, int64_t cols, int32_t planes, ldit_stream stream);
+int ldit_layernorm_f32_planes(const void *X, const void *gamma, const void *beta, void *Y, int64_t rows, int64_t C, float eps,
+                              int32_t planes, ldit_stream stream);
+int ldit_linear_planes(const void *Xp, int64_t lda, const void *Wp, const void *bias, void *Y, int64_t ldy, int64_t M, int64_t N,
+                       int64_t K, int32_t epilogue, const void *lam, const void *R, void *Y2, int32_t planes, ldit_stream stream);
 
 /* ldit_embed_f32's arithmetic on bf16 MFMA operands - the patch embedding of the bf16 / fp8 builds and of the train step
  * (TF:81-90, TF:153-176): x fp32 NCHW is rounded to a bf16 im2col matrix [B*P, in_ch*p*p] in `scratch` (that many bf16, 16-byte

@@ -11,9 +11,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libldit_hip.so")
 
-LDIT_ABI_VERSION = 3
+LDIT_ABI_VERSION = 4
 LDIT_MAX_TAPS = 8
-DTYPE_F32, DTYPE_BF16, DTYPE_FP8 = 0, 1, 3
+DTYPE_F32, DTYPE_BF16, DTYPE_FP8, DTYPE_F32X3, DTYPE_F32X6 = 0, 1, 3, 4, 5
 FP8_A_COUNT = 4
 LDIT_OK, LDIT_EINVAL, LDIT_EWORKSPACE, LDIT_EHIP, LDIT_EUNSUPPORTED = 0, -1, -2, -3, -4
 EPI_BIAS, EPI_BIAS_GELU, EPI_SCALE_RESID, EPI_F32, EPI_GELU_BWD = 0, 1, 2, 4, 5
@@ -57,6 +57,9 @@ SIGNATURES = {
     "ldit_layernorm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp]),
     "ldit_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ldit_embed_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "ldit_split_f32_planes": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
+    "ldit_layernorm_f32_planes": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, C.c_float, _i32, _vp]),
+    "ldit_linear_planes": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _vp]),
     "ldit_embed_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "ldit_tap_to_map_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ldit_tap_to_map_bwd_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),

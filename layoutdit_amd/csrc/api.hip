@@ -130,7 +130,7 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
     // builds: one HBM-bound pass rounds the batch to a bf16 im2col matrix [B P, 3 p p] (into `big`, free until layer 0) and the
     // bf16 MFMA GEMM multiplies it - 16x the fp32 matrix rate for 1.8 - 4.5 % of those steps (the fp32 kernel took 266 us of
     // the 14.6 ms ViT-L/512 step, 60 us of the 1.6 ms fp8 step).
-    if (cfg->dtype != LDIT_F32 && g.Kp % 64 == 0) {
+    if ((cfg->dtype == LDIT_BF16 || cfg->dtype == LDIT_FP8) && g.Kp % 64 == 0) {
         char *patches = ws + wm.big;
         LDIT_RUN(probe, LDIT_K_OTHER, launch_patches_rows(static_cast<const float *>(x), patches, batch, g.in_ch, cfg->img_h, cfg->img_w,
                                                          g.p, stream));
@@ -150,10 +150,36 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
 
     const float scale = 1.0f / sqrtf((float)g.D);
     const bool bf16 = cfg->dtype == LDIT_BF16, fp8 = cfg->dtype == LDIT_FP8;
+    const int S = split_planes_of(cfg->dtype);
+    // split-fp32 builds: the plane products of one output element, SMALLEST FIRST (their sum is formed at its own magnitude
+    // before the leading p0.q0 term arrives): bf16x3 = a1 w0 + a0 w1 + a0 w0; six products = a2 w0 + a1 w1 + a0 w2 + a1 w0 + a0 w1 + a0 w0
+    GemmExtra xs{};
+    if (S == 2) { xs.nseg = 3; xs.seg_a = 0x001u; xs.seg_w = 0x010u; }
+    if (S == 3) { xs.nseg = 6; xs.seg_a = 0x001012u; xs.seg_w = 0x010210u; }
     for (int l = 0; l < g.L; ++l) {
         const PackedLayer &pl = pm.layer[l];
         float *tap = tap_for(l + 1);
-        if (fp8) {
+        if (S) {
+            // fp32 forward on split operands (ldit.h, LDIT_F32X3 / LDIT_F32X6): every GEMM on the bf16 MFMA over the plane products of
+            // its operands, fp32 accumulation; LayerNorm, attention (the fp32 kernel), erf-GELU, LayerScale + residual in fp32.
+            char *ys = ws + wm.y, *bb = ws + wm.big;
+            float *qkv = reinterpret_cast<float *>(bb), *att = reinterpret_cast<float *>(ws + wm.att);
+            GemmExtra xg = xs;
+            xg.nsplit_out = S;
+            LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_splitout(h, F32(pl.ln1_w), F32(pl.ln1_b), ys, M, C, cfg->ln_eps, S, stream));
+            LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(ys, S * C, P + pl.wqkv, F32(pl.bqkv), qkv, 3 * C, M, 3 * C, C, EPI_F32, nullptr,
+                                                            nullptr, nullptr, xs, stream));
+            LDIT_RUN(probe, LDIT_K_ATTENTION,
+                     launch_attention(qkv, qkv + C, qkv + 2 * C, att, batch, g.T, g.H, g.D, 3 * C, 3 * C, 3 * C, C, scale, stream));
+            LDIT_RUN(probe, LDIT_K_OTHER, launch_split_planes(att, C, ys, M, C, S, stream));
+            LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(ys, S * C, P + pl.wo, F32(pl.bo), h, C, M, C, C, EPI_SCALE_RESID, F32(pl.lam1), h,
+                                                            nullptr, xs, stream));
+            LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_splitout(h, F32(pl.ln2_w), F32(pl.ln2_b), ys, M, C, cfg->ln_eps, S, stream));
+            LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(ys, S * C, P + pl.w1, F32(pl.b1), bb, S * F, M, F, C, EPI_GELU_SPLIT, nullptr, nullptr,
+                                                            nullptr, xg, stream));
+            LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(bb, S * F, P + pl.w2, F32(pl.b2), h, C, M, C, F, EPI_SCALE_RESID, F32(pl.lam2), h,
+                                                            tap, xs, stream));
+        } else if (fp8) {
             // fp8 build: LayerNorm, the attention epilogue and the GELU epilogue quantise straight to e4m3 with the
             // calibrated per-tensor scales; q|k|v leave their GEMM as bf16 for the bf16 attention kernel.
             char *y8 = ws + wm.y, *bb = ws + wm.big;
@@ -260,6 +286,11 @@ int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, 
     auto put_mat = [&](size_t off, size_t elt_off, const void *src, size_t rows, size_t cols, size_t sw_off, size_t row0,
                        const char *what, float mul = 1.0f) -> int {
         if (!src) return fail(LDIT_EINVAL, "weights: %s is null", what);
+        if (const int Sp = split_planes_of(cfg->dtype)) {
+            // split-fp32 builds: the matrix as Sp bf16 planes side by side per row; `elt_off` counts fp32 elements of whole rows
+            if (!aligned16(src)) return fail(LDIT_EINVAL, "weights: %s must be 16-byte aligned", what);
+            return launch_split_planes(static_cast<const float *>(src), (int)cols, P + off + elt_off * 2 * Sp, (int)rows, (int)cols, Sp, stream);
+        }
         if (!bf16 && !fp8) return put(off + elt_off * 4, src, rows * cols, what);
         if (!aligned16(src)) return fail(LDIT_EINVAL, "weights: %s must be 16-byte aligned", what);
         if (fp8)
@@ -400,6 +431,42 @@ int ldit_embed_f32(const void *x, const void *patch_w, const void *patch_b, cons
     return embed(g, static_cast<const float *>(x), static_cast<const float *>(patch_w), static_cast<const float *>(patch_b),
                  static_cast<const float *>(cls), static_cast<const float *>(pos), static_cast<float *>(out), (int)B,
                  (int)img_h, (int)img_w, static_cast<hipStream_t>(stream), probe);
+}
+
+int ldit_split_f32_planes(const void *src, int64_t lds, void *dst, int64_t rows, int64_t cols, int32_t planes, ldit_stream stream)
+{
+    if (rows < 0 || cols < 0 || rows * (lds > planes * cols ? lds : planes * cols) >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "split_planes: operand exceeds 2^31 elements");
+    return launch_split_planes(static_cast<const float *>(src), (int)lds, dst, (int)rows, (int)cols, planes, static_cast<hipStream_t>(stream));
+}
+
+int ldit_layernorm_f32_planes(const void *X, const void *gamma, const void *beta, void *Y, int64_t rows, int64_t C, float eps,
+                              int32_t planes, ldit_stream stream)
+{
+    if (C > (1 << 20)) return fail(LDIT_EINVAL, "layernorm: C out of range");
+    return launch_layernorm_splitout(static_cast<const float *>(X), static_cast<const float *>(gamma), static_cast<const float *>(beta), Y,
+                                     rows, (int)C, eps, planes, static_cast<hipStream_t>(stream));
+}
+
+int ldit_linear_planes(const void *Xp, int64_t lda, const void *Wp, const void *bias, void *Y, int64_t ldy, int64_t M, int64_t N,
+                       int64_t K, int32_t epilogue, const void *lam, const void *R, void *Y2, int32_t planes, ldit_stream stream)
+{
+    if (M <= 0 || N <= 0 || K <= 0) return fail(LDIT_EINVAL, "linear_planes: empty problem");
+    if (planes != 2 && planes != 3) return fail(LDIT_EINVAL, "linear_planes: %d planes (2 or 3)", planes);
+    if (M * (ldy > lda ? ldy : lda) >= (1ll << 31) || N * K * planes >= (1ll << 31)) return fail(LDIT_EUNSUPPORTED, "linear_planes: operand exceeds 2^31 elements");
+    if (lda < planes * K) return fail(LDIT_EINVAL, "linear_planes: bad leading dimension");
+    if (!Y || !aligned16(Y) || (Y2 && !aligned16(Y2))) return fail(LDIT_EINVAL, "linear_planes: output null or misaligned");
+    GemmExtra x{};
+    if (planes == 2) { x.nseg = 3; x.seg_a = 0x001u; x.seg_w = 0x010u; }
+    else { x.nseg = 6; x.seg_a = 0x001012u; x.seg_w = 0x010210u; }
+    int epi;
+    if (epilogue == LDIT_EPI_BIAS) epi = EPI_F32;
+    else if (epilogue == LDIT_EPI_SCALE_RESID) epi = EPI_SCALE_RESID;
+    else if (epilogue == LDIT_EPI_BIAS_GELU) { epi = EPI_GELU_SPLIT; x.nsplit_out = planes; }
+    else return fail(LDIT_EINVAL, "linear_planes: unknown epilogue %d", epilogue);
+    if (epi != EPI_GELU_SPLIT && ldy < N) return fail(LDIT_EINVAL, "linear_planes: bad output stride");
+    return launch_gemm_bf16_ex(Xp, (int)lda, Wp, static_cast<const float *>(bias), Y, (int)ldy, (int)M, (int)N, (int)K, epi,
+                               static_cast<const float *>(lam), static_cast<const float *>(R), static_cast<float *>(Y2), x,
+                               static_cast<hipStream_t>(stream));
 }
 
 int ldit_embed_bf16(const void *x, const void *patch_w_bf16, const void *patch_b, const void *cls, const void *pos, void *out,

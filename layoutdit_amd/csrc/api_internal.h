@@ -15,18 +15,22 @@ struct Geo {
     int C, L, H, F, D, p, in_ch, gh, gw, P, T, Kp;   // T tokens per image, Kp = in_ch*p*p
 };
 
+// bf16 planes per fp32 operand of the split-fp32 builds (0 = not a split build)
+inline int split_planes_of(int dtype) { return dtype == LDIT_F32X3 ? 2 : dtype == LDIT_F32X6 ? 3 : 0; }
+
 inline int geometry(const ldit_cfg *cfg, Geo &g)
 {
     if (!cfg) return fail(LDIT_EINVAL, "cfg is null");
-    if (cfg->dtype != LDIT_F32 && cfg->dtype != LDIT_BF16 && cfg->dtype != LDIT_FP8)
-        return fail(LDIT_EUNSUPPORTED, "dtype %d: only fp32 (0), bf16 (1) and fp8 e4m3 (3) are implemented", cfg->dtype);
+    if (cfg->dtype != LDIT_F32 && cfg->dtype != LDIT_BF16 && cfg->dtype != LDIT_FP8 && !split_planes_of(cfg->dtype))
+        return fail(LDIT_EUNSUPPORTED, "dtype %d: only fp32 (0), bf16 (1), fp8 e4m3 (3) and split fp32 (4, 5) are implemented", cfg->dtype);
     g.C = cfg->hidden; g.L = cfg->layers; g.H = cfg->heads; g.F = cfg->mlp; g.p = cfg->patch; g.in_ch = cfg->in_ch;
     if (g.C <= 0 || g.L < 0 || g.H <= 0 || g.F <= 0 || g.p <= 0 || g.in_ch <= 0) return fail(LDIT_EINVAL, "cfg: non-positive dimension");
     if (g.C % g.H) return fail(LDIT_EINVAL, "cfg: hidden %d not divisible by heads %d", g.C, g.H);
     g.D = g.C / g.H;
     if (g.D != 64) return fail(LDIT_EUNSUPPORTED, "cfg: head_dim %d, only 64 is implemented", g.D);
     if (g.C % 32 || g.F % 32) return fail(LDIT_EUNSUPPORTED, "cfg: hidden and mlp must be multiples of 32");
-    if (cfg->dtype == LDIT_BF16 && (g.C % 64 || g.F % 64)) return fail(LDIT_EUNSUPPORTED, "cfg: bf16 needs hidden and mlp multiples of 64");
+    if ((cfg->dtype == LDIT_BF16 || split_planes_of(cfg->dtype)) && (g.C % 64 || g.F % 64))
+        return fail(LDIT_EUNSUPPORTED, "cfg: bf16 needs hidden and mlp multiples of 64");
     if (cfg->dtype == LDIT_FP8 && (g.C % 128 || g.F % 128)) return fail(LDIT_EUNSUPPORTED, "cfg: fp8 needs hidden and mlp multiples of 128");
     if (cfg->img_h <= 0 || cfg->img_w <= 0 || cfg->img_h % g.p || cfg->img_w % g.p)
         return fail(LDIT_EINVAL, "cfg: image %dx%d is not a multiple of patch %d", cfg->img_h, cfg->img_w, g.p);
@@ -55,13 +59,13 @@ inline PackedMap packed_map(const Geo &g, int dtype)
 {
     PackedMap m;
     size_t o = 0;
-    const size_t mat = dtype == LDIT_FP8 ? 1 : dtype == LDIT_BF16 ? 2 : 4;
+    const size_t mat = dtype == LDIT_FP8 ? 1 : dtype == LDIT_BF16 ? 2 : split_planes_of(dtype) ? 2 * (size_t)split_planes_of(dtype) : 4;
     auto take = [&](size_t n, size_t elt) { size_t at = o; o += up(n * elt, 16); return at; };
     m.patch_w = take((size_t)g.C * g.Kp, 4);
     m.patch_b = take(g.C, 4);
     m.cls = take(g.C, 4);
     m.pos = take((size_t)g.T * g.C, 4);
-    m.patch_w16 = dtype != LDIT_F32 ? take((size_t)g.C * g.Kp, 2) : 0;
+    m.patch_w16 = (dtype == LDIT_BF16 || dtype == LDIT_FP8) ? take((size_t)g.C * g.Kp, 2) : 0;
     m.layer.resize(g.L);
     for (int l = 0; l < g.L; ++l) {
         PackedLayer &pl = m.layer[l];
@@ -81,7 +85,7 @@ inline PackedMap packed_map(const Geo &g, int dtype)
     return m;
 }
 
-struct Workspace { size_t h, y, big, total; };   // byte offsets
+struct Workspace { size_t h, y, big, att, total; };   // byte offsets (att: split-fp32 builds only)
 
 inline Workspace workspace_map(const Geo &g, int batch, int dtype)
 {
@@ -92,10 +96,21 @@ inline Workspace workspace_map(const Geo &g, int batch, int dtype)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += up(bytes, 256); return at; };
     w.h = take(M * g.C * 4);       // residual stream (always fp32)
+    if (const size_t S = (size_t)split_planes_of(dtype)) {
+        // split-fp32 builds: y = the S bf16 planes of the LayerNorm / attention output; big = fp32 q|k|v, later the S planes of
+        // the MLP hidden; att = the fp32 attention output before it is split
+        w.y = take(M * g.C * 2 * S);
+        const size_t qkv = M * 3 * g.C * 4, hid = M * g.F * 2 * S;
+        w.big = take(qkv > hid ? qkv : hid);
+        w.att = take(M * g.C * 4);
+        w.total = o;
+        return w;
+    }
     w.y = take(M * g.C * act);     // LayerNorm output, then attention output
     size_t big = M * wide * act;   // fused q|k|v, later the MLP hidden (never live together)
     if (dtype != LDIT_F32 && big < (size_t)batch * g.P * g.Kp * 2) big = (size_t)batch * g.P * g.Kp * 2;   // before layer 0: bf16 im2col of the batch
     w.big = take(big);
+    w.att = 0;
     w.total = o;
     return w;
 }

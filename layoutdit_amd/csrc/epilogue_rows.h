@@ -17,7 +17,8 @@ typedef __bf16 epi_bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int EPI_ROW_BYTES = 272;                    // 64 fp32 + 16 B pad: 68 dwords -> b128 writes of 8 lanes hit 32 banks once
 constexpr int EPI_WAVE_BYTES = 32 * EPI_ROW_BYTES;    // one 32 x 64 slab per wave
 
-enum { EPI_OUT_BF16 = 0, EPI_OUT_FP8 = 1, EPI_OUT_F32 = 2 };
+enum { EPI_OUT_BF16 = 0, EPI_OUT_FP8 = 1, EPI_OUT_F32 = 2,
+       EPI_OUT_SPLIT = 3 };   // x.nsplit_out bf16 planes of the fp32 value, side by side in the row (split-fp32 build)
 
 // acc: the wave's TM x TN tiles; (mw, nw): its first row / column; buf: EPI_WAVE_BYTES of LDS private to this wave.
 // The RAW accumulators travel through LDS; all arithmetic happens on the read-back side, where a lane owns four fixed
@@ -94,6 +95,10 @@ __device__ __forceinline__ void store_rows_via_lds(const f32x16 (&acc)[TM][TN], 
                         for (int e = 0; e < 4; ++e) v[e] = gelu_lp(v[e]);
                     }
                 }
+                if (EPI == EPI_GELU_SPLIT) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
                 if (EPI == EPI_GELU_BWD) {
                     const epi_bf16x4 a = *reinterpret_cast<const epi_bf16x4 *>(
                         static_cast<const __bf16 *>(x.aux) + ((unsigned)(mw + 32 * i + row) * (unsigned)x.ldaux + n));
@@ -114,6 +119,16 @@ __device__ __forceinline__ void store_rows_via_lds(const f32x16 (&acc)[TM][TN], 
                     }
                     *reinterpret_cast<f32x4 *>(static_cast<float *>(Yv) + o) = v;
                     if (Y2) *reinterpret_cast<f32x4 *>(Y2 + o) = v;
+                } else if (OUT == EPI_OUT_SPLIT) {
+                    // planes p0 = bf16(v), p1 = bf16(v - p0), (p2 = bf16(v - p0 - p1)): plane s at column s * (ldy / nsplit_out)
+                    const unsigned plane = (unsigned)ldy / (unsigned)x.nsplit_out;
+                    f32x4 r = v;
+                    for (int sp = 0; sp < x.nsplit_out; ++sp) {
+                        const epi_bf16x4 pk = {(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]};
+                        *reinterpret_cast<epi_bf16x4 *>(static_cast<__bf16 *>(Yv) + o + sp * plane) = pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r[e] -= (float)pk[e];
+                    }
                 } else if (OUT == EPI_OUT_FP8) {
                     *reinterpret_cast<unsigned *>(static_cast<unsigned char *>(Yv) + o) =
                         pack_fp8x4(v[0] * oinv, v[1] * oinv, v[2] * oinv, v[3] * oinv);

@@ -12,6 +12,7 @@
 //
 // Epilogues: bias -> bf16 ; bias + erf-GELU -> bf16 ; R + lam (.) (acc + bias) -> fp32 (in place on the fp32 residual
 // stream, optional fp32 tap copy).
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -93,17 +94,29 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
         } else {
             int gn = n0 + row - BM;
             gn = gn < p.N ? gn : p.N - 1;
-            src[u] = (unsigned)gn * (unsigned)p.K + c * 8;
+            src[u] = (unsigned)gn * (unsigned)p.ldw + c * 8;
         }
     }
-    auto issue_range = [&](int stage, int k0, int lo, int hi) {
+    // k-tile t of the product -> column offsets into the A row and the W row.  Ordinary GEMM: both t * 64.  Split-fp32 operands
+    // (GemmExtra::nseg): segment t / nk selects one bf16 plane of each operand, t % nk walks its K columns.  All wave-uniform.
+    const int nseg = p.x.nseg > 0 ? p.x.nseg : 1;
+    const int nkt = nk * nseg;
+    auto tile_off = [&](int t, unsigned &ka, unsigned &kw) {
+        t = t < nkt ? t : nkt - 1;
+        int seg = 0;
+        if (p.x.nseg > 1) { seg = t / nk; t -= seg * nk; }
+        ka = (unsigned)(((p.x.seg_a >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)t * BKB);
+        kw = (unsigned)(((p.x.seg_w >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)t * BKB);
+    };
+    auto issue_range = [&](int stage, unsigned ka, unsigned kw, int lo, int hi) {
         char *base = smem + stage * (ROWS * ROWB);
 #pragma unroll
         for (int u = 0; u < NLW; ++u) {
             if (u < lo || u >= hi) continue;
             const int piece = (wave % LW) + LW * u;
-            const bf16_t *opnd = 8 * piece < BM ? p.A : p.W;
-            glds16h(opnd + (src[u] + (unsigned)k0), base + piece * 1024);
+            const bool isA = 8 * piece < BM;
+            const bf16_t *opnd = isA ? p.A : p.W;
+            glds16h(opnd + (src[u] + (isA ? ka : kw)), base + piece * 1024);
         }
     };
 
@@ -150,21 +163,24 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     // pieces issued in steps 3 / 0 / 1; a SPLIT loader issues all of them right behind the hand-over (twice the pieces: the last
     // ones need the whole k-tile to land)
     constexpr int D3 = SPLIT ? NP : (NP + 2) / 3, D0 = SPLIT ? 0 : (NP - D3 + 1) / 2, D1 = NP - D3 - D0;
-    issue_range(0, 0, 0, NP);
-    issue_range(1, (nk > 1 ? 1 : 0) * BKB, 0, D3);
+    unsigned ka1, kw1, ka2, kw2;
+    tile_off(0, ka1, kw1);
+    issue_range(0, ka1, kw1, 0, NP);
+    tile_off(1, ka1, kw1);
+    issue_range(1, ka1, kw1, 0, D3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tile has landed before anybody reads it
     __syncthreads();
 #ifdef LDIT_GEMM_STAMPS
     st_loop0 = __builtin_amdgcn_s_memtime();
 #endif
     load_frags(0, 0, xa0, wb0);
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        const int k1 = (kt + 1 < nk ? kt + 1 : nk - 1) * BKB, k2 = (kt + 2 < nk ? kt + 2 : nk - 1) * BKB;
+        tile_off(kt + 2, ka2, kw2);
         __builtin_amdgcn_sched_barrier(0);
         // ---- step 0
         load_frags(cur, 1, xa1, wb1);
-        issue_range(cur ^ 1, k1, D3, D3 + D0);
+        issue_range(cur ^ 1, ka1, kw1, D3, D3 + D0);
         mfma_step(xa0, wb0);
 #pragma unroll
         for (int g = 0; g < NF; ++g) {
@@ -180,7 +196,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
         __builtin_amdgcn_sched_barrier(0);
         // ---- step 1
         load_frags(cur, 2, xa0, wb0);
-        issue_range(cur ^ 1, k1, D3 + D0, NP);
+        issue_range(cur ^ 1, ka1, kw1, D3 + D0, NP);
         mfma_step(xa1, wb1);
 #pragma unroll
         for (int g = 0; g < NF; ++g) {
@@ -223,7 +239,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
 #endif
         // ---- step 3: MFMAs of the last fragments | first fragments of tile kt+1 | first DMA pieces of tile kt+2 -> stage cur
         load_frags(cur ^ 1, 0, xa0, wb0);
-        issue_range(cur, k2, 0, D3);
+        issue_range(cur, ka2, kw2, 0, D3);
+        ka1 = ka2; kw1 = kw2;
         mfma_step(xa1, wb1);
 #pragma unroll
         for (int g = 0; g < NF; ++g) {
@@ -250,7 +267,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
     if (cols_in && m0 + BM <= p.M && !p.direct_epi) {
         __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
-        store_rows_via_lds<TM, TN, EPI, f32_out<EPI>() ? EPI_OUT_F32 : EPI_OUT_BF16>(
+        store_rows_via_lds<TM, TN, EPI, f32_out<EPI>() ? EPI_OUT_F32 : EPI == EPI_GELU_SPLIT ? EPI_OUT_SPLIT : EPI_OUT_BF16>(
             acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, nullptr, p.ldy, mw, nw, lane, 1.0f, 1.0f, p.x);
     } else if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
     else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
@@ -337,7 +354,8 @@ int launch_tail(const GemmArgsH &a, hipStream_t stream)
 template <int EPI>
 int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
 {
-    if (a.M <= 64 && a.x.splits == 1 && !diag().bf16_tile_env) return launch_tail<EPI>(a, stream);
+    // (split-fp32 operands walk their plane segments in the tile kernels only)
+    if (a.M <= 64 && a.x.splits == 1 && a.x.nseg == 0 && !diag().bf16_tile_env) return launch_tail<EPI>(a, stream);
     // Time model fitted to scripts/gemm_bf16_bench.py on ViT-B / ViT-L shapes, M = 3 k .. 25 k (profiles/README.md), in us:
     //   256 x 256, 8 waves (one workgroup per CU):  strict rounds of 256 tiles, each  a[epi] + 19.5e-3 K
     //   128 x 128 (two per CU, they overlap each other's prologue / epilogue):  rounds of 256 tiles, each  r[epi] + 7.6e-3 K,
@@ -346,10 +364,11 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
     // workgroups per CU, a barrier-phased ping-pong of the two waves per SIMD, a v_mfma_f32_16x16x32_bf16 build and a
     // four-wave 256 x 256 tile - none beat this kernel on any shape; the 256 x 128 tile stays selectable for experiments.
     // (EPI_EMBED and EPI_F32 priced like the residual epilogue, EPI_GELU_BWD like the GELU one)
-    const double a256[6] = {19.0, 18.5, 25.0, 25.0, 25.0, 18.5}, r128[6] = {5.2, 5.0, 7.7, 7.7, 7.7, 5.0};
+    const double a256[7] = {19.0, 18.5, 25.0, 25.0, 25.0, 18.5, 25.0}, r128[7] = {5.2, 5.0, 7.7, 7.7, 7.7, 5.0, 7.7};
     const long sp = a.x.splits;
+    const int depth = a.x.nseg > 1 ? a.K * a.x.nseg : a.K;     // k-depth of one output element (all plane segments)
     const long t256 = sp * ((a.M + 255) / 256) * ((a.N + 255) / 256), t128 = sp * ((a.M + 127) / 128) * ((a.N + 127) / 128);
-    const double Ks = (double)a.K / (double)sp;            // k-depth one block walks
+    const double Ks = (double)depth / (double)sp;           // k-depth one block walks
     const double c256 = (double)((t256 + 255) / 256) * (a256[EPI] + 19.5e-3 * Ks);
     double c128 = (double)((t128 + 255) / 256) * (r128[EPI] + 7.6e-3 * Ks);
     if (c128 < 5.0 + 11.4e-3 * Ks) c128 = 5.0 + 11.4e-3 * Ks;
@@ -389,7 +408,39 @@ __global__ void __launch_bounds__(256) cvt_f32_bf16(const float *__restrict__ sr
     }
 }
 
+// fp32 [rows, cols] (row stride lds) -> `S` bf16 planes side by side, [rows, S * cols]: x ~= p0 + p1 (+ p2).  4 elements per thread.
+template <int S>
+__global__ void __launch_bounds__(256) split_planes(const float *__restrict__ src, int lds, bf16_t *__restrict__ dst, int rows, int cols)
+{
+    const int c4 = cols >> 2;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * c4) return;
+    const int r = (int)(i / c4), c = (int)(i - (size_t)r * c4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)r * lds + c);
+    bf16_t *d = dst + (size_t)r * (S * cols) + c;
+#pragma unroll
+    for (int sp = 0; sp < S; ++sp) {
+        const bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4 *>(d + sp * cols) = pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] -= (float)pk[e];
+    }
+}
+
 }  // namespace
+
+int launch_split_planes(const float *src, int lds, void *dst, int rows, int cols, int planes, hipStream_t stream)
+{
+    if (rows <= 0 || cols <= 0) return LDIT_OK;
+    if (!src || !dst || (cols & 3) || (lds & 3) || lds < cols || !aligned16(src) || (reinterpret_cast<uintptr_t>(dst) & 7u))
+        return fail(LDIT_EINVAL, "split_planes: null / misaligned operand or cols not a multiple of 4");
+    const unsigned blocks = (unsigned)(((size_t)rows * (cols >> 2) + 255) / 256);
+    if (planes == 2) hipLaunchKernelGGL(split_planes<2>, dim3(blocks), dim3(256), 0, stream, src, lds, static_cast<bf16_t *>(dst), rows, cols);
+    else if (planes == 3) hipLaunchKernelGGL(split_planes<3>, dim3(blocks), dim3(256), 0, stream, src, lds, static_cast<bf16_t *>(dst), rows, cols);
+    else return fail(LDIT_EINVAL, "split_planes: %d planes (2 or 3)", planes);
+    LDIT_HIP_CHECK(hipGetLastError());
+    return LDIT_OK;
+}
 
 static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const float *bias, void *Y, int ldy, int M, int N, int K,
                                 int epi, const float *lam, const float *R, float *Y2, const GemmExtra &x, hipStream_t stream);
@@ -404,7 +455,8 @@ int launch_gemm_bf16_ex(const void *A, int lda, const void *W, const float *bias
     const int rem = M % 256;
     const long nbn = (N + 255) / 256, full = ((long)M / 256 + 1) * nbn, mainp = ((long)M / 256) * nbn;
     // (the patch-embedding epilogue maps rows by their GLOBAL index: never peeled)
-    if (rem != 0 && rem <= 64 && M > 256 && x.splits == 1 && epi != EPI_EMBED && (full + 255) / 256 > (mainp + 255) / 256) {   // peel only when it saves a round
+    // (nor is a split-fp32 product: the tail kernel walks one K range)
+    if (rem != 0 && rem <= 64 && M > 256 && x.splits == 1 && epi != EPI_EMBED && x.nseg == 0 && (full + 255) / 256 > (mainp + 255) / 256) {   // peel only when it saves a round
         const int main_rows = M - rem;
         const size_t out_elt = (epi == EPI_SCALE_RESID || epi == EPI_F32) ? 4 : 2;
         int rc = launch_gemm_bf16_one(A, lda, W, bias, Y, ldy, main_rows, N, K, epi, lam, R, Y2, x, stream);
@@ -442,6 +494,18 @@ static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const flo
     GemmArgsH a{};
     a.A = static_cast<const bf16_t *>(A); a.W = static_cast<const bf16_t *>(W); a.Y = Y; a.Y2 = Y2; a.bias = bias; a.lam = lam;
     a.R = R; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldy = ldy; a.x = x;
+    a.ldw = K;
+    if (x.nseg != 0) {
+        // split-fp32 operands: the planes of a row lie side by side; the widest plane index fixes the W row stride
+        if (x.nseg < 1 || x.nseg > 8 || x.splits != 1) return fail(LDIT_EINVAL, "gemm_bf16: bad plane-segment list");
+        unsigned pa = 0, pw = 0;
+        for (int g = 0; g < x.nseg; ++g) {
+            pa = std::max(pa, (x.seg_a >> (4 * g)) & 15u);
+            pw = std::max(pw, (x.seg_w >> (4 * g)) & 15u);
+        }
+        if ((long)lda < (long)(pa + 1) * K) return fail(LDIT_EINVAL, "gemm_bf16: lda too small for the A planes");
+        a.ldw = (int)(pw + 1) * K;
+    }
     a.direct_epi = diag().direct_epi ? 1 : 0;
     switch (epi) {
         case EPI_BIAS: return launch_h_tiled<EPI_BIAS>(a, stream);
@@ -450,6 +514,10 @@ static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const flo
             if (!lam || !R) return fail(LDIT_EINVAL, "gemm_bf16: scale+residual epilogue needs lam and R");
             return launch_h_tiled<EPI_SCALE_RESID>(a, stream);
         case EPI_F32: return launch_h_tiled<EPI_F32>(a, stream);
+        case EPI_GELU_SPLIT:
+            if (x.nsplit_out < 2 || x.nsplit_out > 3 || ldy != x.nsplit_out * N || (N & 3))
+                return fail(LDIT_EINVAL, "gemm_bf16: split GELU epilogue needs 2 or 3 output planes and ldy = planes * N");
+            return launch_h_tiled<EPI_GELU_SPLIT>(a, stream);
         case EPI_EMBED:
             if (!x.pos || x.patches <= 0 || M % x.patches || !aligned16(x.pos) || (ldy & 3))
                 return fail(LDIT_EINVAL, "gemm_bf16: patch-embedding epilogue needs pos, patches | M and 16-byte rows");

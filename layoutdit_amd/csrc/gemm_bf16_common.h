@@ -115,6 +115,10 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
                             if (n + e < p.N) yp[o + e] = (bf16_t)sv[e];
                     }
                 }
+                if (EPI == EPI_GELU_SPLIT) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
                 if (EPI == EPI_GELU_BWD) {
                     const bf16_t *ax = static_cast<const bf16_t *>(p.x.aux) + ((unsigned)m * (unsigned)p.x.ldaux + (unsigned)n);
 #pragma unroll
@@ -136,6 +140,20 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (n + e < p.N) { y[o + e] = v[e]; if (dual) p.Y2[o + e] = v[e]; }
+                    }
+                } else if (EPI == EPI_GELU_SPLIT) {
+                    bf16_t *y = static_cast<bf16_t *>(p.Y);
+                    const unsigned plane = (unsigned)p.ldy / (unsigned)p.x.nsplit_out;
+                    f32x4 r = v;
+                    for (int sp = 0; sp < p.x.nsplit_out; ++sp) {
+                        const bf16x4 pk = {(bf16_t)r[0], (bf16_t)r[1], (bf16_t)r[2], (bf16_t)r[3]};
+                        if (MODE != 2) *reinterpret_cast<bf16x4 *>(y + o + sp * plane) = pk;
+                        else
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < p.N) y[o + sp * plane + e] = pk[e];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r[e] -= (float)pk[e];
                     }
                 } else {
                     bf16_t *y = static_cast<bf16_t *>(p.Y);

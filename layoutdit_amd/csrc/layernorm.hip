@@ -20,7 +20,8 @@ __device__ __forceinline__ float wave_sum(float v)
 typedef __bf16 ln_bf16x4 __attribute__((ext_vector_type(4)));
 
 // OUT = 1: the normalised row is rounded to bf16 (operand of the bf16 GEMMs); OUT = 2: quantised to fp8 e4m3 codes of
-// y / *qscale (operand of the fp8 GEMMs, saturating); statistics and affine stay fp32.
+// y / *qscale (operand of the fp8 GEMMs, saturating); OUT = 3 / 4: written as 2 / 3 bf16 planes y ~= p0 + p1 (+ p2) side by
+// side in a row of 2 C / 3 C elements (operand of the split-fp32 GEMMs); statistics and affine stay fp32.
 template <int VPL, int OUT, int RPW>
 __global__ void __launch_bounds__(256) layernorm_rows(const float *__restrict__ X, const float *__restrict__ g,
                                                       const float *__restrict__ b, void *__restrict__ Yv, int64_t rows,
@@ -81,7 +82,17 @@ __global__ void __launch_bounds__(256) layernorm_rows(const float *__restrict__ 
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = v[r][u][e] * rstd * gg[e] + bb[e];
-                if (OUT == 2) {
+                if (OUT >= 3) {
+                    constexpr int S = OUT == 3 ? 2 : 3;
+                    __bf16 *yr = static_cast<__bf16 *>(Yv) + row * (int64_t)(S * C);
+#pragma unroll
+                    for (int sp = 0; sp < S; ++sp) {
+                        const ln_bf16x4 pk = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                        reinterpret_cast<ln_bf16x4 *>(yr + sp * C)[idx] = pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] -= (float)pk[e];
+                    }
+                } else if (OUT == 2) {
                     const float qi = 1.0f / qscale[0];
                     reinterpret_cast<unsigned *>(static_cast<unsigned char *>(Yv) + row * C)[idx] =
                         pack_fp8x4(o[0] * qi, o[1] * qi, o[2] * qi, o[3] * qi);
@@ -129,6 +140,14 @@ int launch_layernorm_bf16out(const float *X, const float *g, const float *b, voi
                              hipStream_t stream)
 {
     return launch_ln<1>(X, g, b, Y, rows, C, eps, nullptr, stream);
+}
+
+int launch_layernorm_splitout(const float *X, const float *g, const float *b, void *Y, int64_t rows, int C, float eps, int planes,
+                              hipStream_t stream)
+{
+    if (planes == 2) return launch_ln<3>(X, g, b, Y, rows, C, eps, nullptr, stream);
+    if (planes == 3) return launch_ln<4>(X, g, b, Y, rows, C, eps, nullptr, stream);
+    return fail(LDIT_EINVAL, "layernorm: %d output planes (2 or 3)", planes);
 }
 
 int launch_layernorm_fp8out(const float *X, const float *g, const float *b, void *Y, int64_t rows, int C, float eps,

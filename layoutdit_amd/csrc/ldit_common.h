@@ -129,7 +129,8 @@ enum AMode { A_ROWMAJOR = 0, A_PATCH = 1,
              A_CONV3 = 2 };   // fp32 general kernel only: implicit im2col of a 3x3 / pad 1 convolution over an NHWC map
 enum Epi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_SCALE_RESID = 2, EPI_EMBED = 3,
            EPI_F32 = 4,        // bf16 GEMM only: Y fp32 = acc (+ bias); dgrad into LayerNorm backward, wgrad slabs
-           EPI_GELU_BWD = 5 }; // bf16 GEMM only: Y bf16 = acc * aux, aux = gelu'(pre-activation) saved by the forward
+           EPI_GELU_BWD = 5,   // bf16 GEMM only: Y bf16 = acc * aux, aux = gelu'(pre-activation) saved by the forward
+           EPI_GELU_SPLIT = 6 }; // bf16 GEMM, split-fp32 build only: Y = split_bf16(gelu_erf(acc + bias)), `nsplit_out` bf16 planes per row
 
 // Optional operands of the bf16 GEMM used by the train step (training.hip); all null / 1 for inference.
 struct GemmExtra {
@@ -144,7 +145,26 @@ struct GemmExtra {
     // b * (patches + 1) + 1 + i of the fp32 output with pos[1 + i] added (TF:153-176; the CLS rows are launch_cls_rows')
     const float *pos = nullptr;        // fp32 [patches + 1, N], row stride ldy
     int patches = 0;
+    // Split-fp32 build (LDIT_F32X3 / LDIT_F32X6, api.hip): an fp32 operand x is held as S bf16 PLANES x ~= p0 + p1 (+ p2), p0 = bf16(x),
+    // p1 = bf16(x - p0), ... stored side by side per row (A: [M, S K], W: [N, S K]).  The product is the sum of `nseg` plane
+    // products in a fixed order: the k-loop walks segment g = 0 .. nseg-1 over the K columns of A-plane seg_a(g) and W-plane
+    // seg_w(g) (4 bits each, segment 0 in the low nibble) - ONE accumulation chain per output element whatever tile it falls in.
+    // K in the launch arguments stays the per-plane depth.  nseg = 0: ordinary bf16 GEMM.
+    int nseg = 0;
+    unsigned seg_a = 0, seg_w = 0;
+    int nsplit_out = 0;                // EPI_GELU_SPLIT: planes of the output row (row stride ldy = nsplit_out * N)
 };
+
+// x ~= p[0] + p[1] (+ p[2]): the bf16 planes of the split-fp32 build.  Every subtraction is exact in fp32.
+template <int S>
+__device__ __forceinline__ void split_bf16_planes(float x, __bf16 (&p)[S])
+{
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        p[s] = (__bf16)x;
+        x -= (float)p[s];
+    }
+}
 
 struct GemmArgs {
     const float *A;      // [M, K] row-major (A_ROWMAJOR) or the NCHW image batch (A_PATCH)
@@ -204,6 +224,10 @@ int launch_gemm_bf16_ex(const void *A, int lda, const void *W, const float *bias
 int launch_gemm_bf16_tr(const void *A, int lda, bool a_reduction_major, const void *W, int ldw, const float *bias, void *Y, int ldy,
                         int M, int N, int K, int epi, const GemmExtra &x, hipStream_t stream);
 int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream, float mul = 1.0f);
+// split-fp32 build: dst bf16 [rows, planes * cols] = the `planes` bf16 planes of src fp32 [rows, cols] (row stride lds) side by side
+int launch_split_planes(const float *src, int lds, void *dst, int rows, int cols, int planes, hipStream_t stream);
+int launch_layernorm_splitout(const float *X, const float *g, const float *b, void *Y, int64_t rows, int C, float eps, int planes,
+                              hipStream_t stream);
 // fp8: the per-tensor part of the accumulator's dequantisation is d_act[0] when d_act is non-null (device), else the host
 // value ab_scale; d_wrow (device, [N], optional) multiplies per-output-channel weight scales onto it; d_out (device, 1
 // float: scale of the fp8 output) overrides out_inv_scale.

@@ -49,7 +49,7 @@ class _Affine(nn.Module):
             self.register_parameter("bias", None)
 
 
-_DTYPES = {"f32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16, "fp8": _lib.DTYPE_FP8}
+_DTYPES = {"f32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16, "fp8": _lib.DTYPE_FP8, "f32x3": _lib.DTYPE_F32X3, "f32x6": _lib.DTYPE_F32X6}
 
 
 class _Holder(nn.Module):
@@ -71,6 +71,11 @@ class DiTEncoder(nn.Module):
         (bf16 GEMM / attention operands with fp32 accumulation, residual stream, LayerNorm and softmax; parameters and
         returned taps stay fp32) or ``"fp8"`` (the four GEMMs of a layer on fp8 e4m3 operands with per-tensor scales,
         attention on bf16; needs one ``calibrate_fp8(sample_batch)`` call before the first forward).
+        ``"f32x3"`` / ``"f32x6"``: the fp32 forward with every GEMM operand held as two / three bf16 planes and every product
+        formed from three / six plane products on the bf16 MFMA (16x the fp32 matrix rate) with fp32 accumulation; LayerNorm,
+        attention, erf-GELU and the residual stream exactly as ``"f32"``.  ``"f32x6"`` has the error of fp32 arithmetic (5e-7 vs
+        float64), ``"f32x3"`` 3-5e-6 - inside the fp32 build's own parity gates, 200x inside the reference's 1e-3 - at more than
+        twice the speed of ``"f32"`` (include/ldit.h, LDIT_F32X3).
 
         TRAINING (``.train()`` + ``loss.backward()``, ref trainer.py:168-180) is mixed precision for the ``"f32"`` and
         ``"bf16"`` builds alike: bf16 MFMA operands, fp32 accumulation, fp32 residual stream / LayerNorm / softmax /
@@ -80,7 +85,7 @@ class DiTEncoder(nn.Module):
         tests/test_gpu_train.py).  The ``"fp8"`` build is inference only."""
         super().__init__()
         if compute_dtype not in _DTYPES:
-            raise ValueError(f"compute_dtype {compute_dtype!r}: expected 'f32', 'bf16' or 'fp8'")
+            raise ValueError(f"compute_dtype {compute_dtype!r}: expected 'f32', 'f32x3', 'f32x6', 'bf16' or 'fp8'")
         self.compute_dtype = compute_dtype
         self.config = config or DiTConfig()
         cfg = self.config

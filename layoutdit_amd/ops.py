@@ -239,6 +239,48 @@ def linear_bf16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
     return out
 
 
+def split_planes(x: torch.Tensor, planes: int) -> torch.Tensor:
+    """fp32 [rows, cols] -> bf16 [rows, planes * cols]: p0 = bf16(x), p1 = bf16(x - p0), (p2 = bf16(x - p0 - p1)) side by side."""
+    lib = _lib.load()
+    x = _req(x, "x")
+    rows, cols = x.shape
+    out = torch.empty((rows, planes * cols), device=x.device, dtype=torch.bfloat16)
+    _launch(_device(x), lib.ldit_split_f32_planes, _ptr(x), cols, _ptr(out), rows, cols, planes)
+    return out
+
+
+def layernorm_planes(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, planes: int) -> torch.Tensor:
+    lib = _lib.load()
+    x, gamma, beta = _req(x, "x"), _req(gamma, "gamma"), _req(beta, "beta")
+    rows, Cc = x.shape
+    out = torch.empty((rows, planes * Cc), device=x.device, dtype=torch.bfloat16)
+    _launch(_device(x, gamma, beta), lib.ldit_layernorm_f32_planes, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), rows, Cc, float(eps), planes)
+    return out
+
+
+def linear_planes(xp: torch.Tensor, wp: torch.Tensor, planes: int, bias: Optional[torch.Tensor] = None, epilogue: int = _lib.EPI_BIAS,
+                  lam: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The GEMM of the split-fp32 builds: ``xp`` [M, planes*K], ``wp`` [N, planes*K] bf16 planes of fp32 operands (``split_planes``);
+    3 (planes = 2) or 6 (planes = 3) plane products on the bf16 MFMA, fp32 accumulation.  fp32 result (bias / scale+residual),
+    or the planes of erf-GELU(.) as bf16 [M, planes*N] (bias+GELU)."""
+    lib = _lib.load()
+    for t, n in ((xp, "xp"), (wp, "wp")):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
+            raise ValueError(f"{n}: expected a contiguous bfloat16 GPU tensor")
+    M, K = xp.shape[0], xp.shape[1] // planes
+    N = wp.shape[0]
+    if out is None:
+        out = (torch.empty((M, planes * N), device=xp.device, dtype=torch.bfloat16) if epilogue == _lib.EPI_BIAS_GELU
+               else torch.empty((M, N), device=xp.device, dtype=torch.float32))
+    for t, n in ((bias, "bias"), (lam, "lam"), (residual, "residual"), (out2, "out2")):
+        if t is not None:
+            _req(t, n)
+    _launch(_device(xp, wp, bias, lam, residual, out, out2), lib.ldit_linear_planes, _ptr(xp), planes * K, _ptr(wp), _ptr(bias), _ptr(out),
+            out.shape[1], M, N, K, epilogue, _ptr(lam), _ptr(residual), _ptr(out2), planes)
+    return out
+
+
 FP8_MAX = 448.0          # largest finite e4m3 magnitude
 
 

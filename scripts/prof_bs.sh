@@ -5,7 +5,7 @@ B=${1:-1}; TAG=${2:-bs$B}
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $ROOT/gpurun_out/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o $TAG -- python3 $ROOT/bench.py --batch $B --steps 20 --warmup 3 --cpu-sample 0 --no-roofline-pass > $ROOT/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o $TAG -- python3 $ROOT/bench.py --batch $B --steps 20 --warmup 3 --cpu-sample 0 --no-roofline-pass --no-split-fp32 > $ROOT/gpurun_out/prof_$TAG.log 2>&1
 echo "rc=$?"
 find $ROOT/gpurun_out/prof_$TAG -name '*kernel_trace.csv' -delete
 python3 - <<PY

@@ -12,13 +12,13 @@ mkdir -p $ROOT/gpurun_out
 python3 $ROOT/bench.py "$@" > $ROOT/gpurun_out/${TAG}_bench.json 2> $ROOT/gpurun_out/${TAG}_bench.err; echo "bench rc=$?"
 cut -c1-260 $ROOT/gpurun_out/${TAG}_bench.json
 rm -rf $ROOT/gpurun_out/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o $TAG -- python3 $ROOT/bench.py "$@" --steps 5 --warmup 2 --cpu-sample 0 --no-roofline-pass > $ROOT/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o $TAG -- python3 $ROOT/bench.py "$@" --steps 5 --warmup 2 --cpu-sample 0 --no-roofline-pass --no-split-fp32 > $ROOT/gpurun_out/prof_$TAG.log 2>&1
 echo "kernel-trace rc=$?"
 cp "$(find $ROOT/gpurun_out/prof_$TAG -name '*kernel_stats.csv' | head -1)" $ROOT/gpurun_out/${TAG}_kernel_stats.csv
 run() {  # name counters...
   local name=$1; shift
   rm -rf $ROOT/gpurun_out/pmc_${TAG}_$name
-  rocprofv3 --pmc "$@" --output-format csv -d $ROOT/gpurun_out/pmc_${TAG}_$name -o $name -- python3 $ROOT/bench.py "${BARGS[@]}" --steps 2 --warmup 1 --cpu-sample 0 --no-roofline-pass > $ROOT/gpurun_out/pmc_${TAG}_$name.log 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d $ROOT/gpurun_out/pmc_${TAG}_$name -o $name -- python3 $ROOT/bench.py "${BARGS[@]}" --steps 2 --warmup 1 --cpu-sample 0 --no-roofline-pass --no-split-fp32 > $ROOT/gpurun_out/pmc_${TAG}_$name.log 2>&1
   echo "pmc pass $name rc=$?"
 }
 BARGS=("$@")

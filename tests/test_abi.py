@@ -60,7 +60,7 @@ def test_sizing_is_host_side_and_consistent():
     (lambda c: setattr(c, "heads", 24), "head_dim"),
     (lambda c: setattr(c, "img_h", 230), "multiple of patch"),
     (lambda c: setattr(c, "n_taps", 9), "n_taps"),
-    (lambda c: setattr(c, "dtype", 5), "dtype"),
+    (lambda c: setattr(c, "dtype", 7), "dtype"),
 ])
 def test_bad_geometry_is_rejected_with_a_message(mutate, fragment):
     lib = _lib.load()
@@ -156,6 +156,15 @@ def test_low_precision_builds_keep_the_checkpoint_surface_and_size_their_buffers
     assert lib.ldit_packed_bytes(C.byref(lc)) == f32 - 2 * mats + pw16
     lc.dtype = _lib.DTYPE_FP8
     assert lib.ldit_packed_bytes(C.byref(lc)) == f32 - 3 * mats + pw16 + 12 * (32 + 4 * (3 * 768 + 768 + 3072 + 768))   # + scales
+    # split-fp32 builds: every matrix as 2 / 3 bf16 planes (4 / 6 bytes per element), no bf16 patch projection (fp32 embedding)
+    lc.dtype = _lib.DTYPE_F32X3
+    assert lib.ldit_packed_bytes(C.byref(lc)) == f32
+    lc.dtype = _lib.DTYPE_F32X6
+    assert lib.ldit_packed_bytes(C.byref(lc)) == f32 + 2 * mats
+    for dt in (_lib.DTYPE_F32X3, _lib.DTYPE_F32X6):
+        lc.dtype = dt
+        assert lib.ldit_workspace_bytes(C.byref(lc), 2) > 0
+    lc.dtype = _lib.DTYPE_FP8
     lt = _cfg(cfgs.vit_tiny())                       # hidden 192: not a multiple of the fp8 k-tile
     lt.dtype = _lib.DTYPE_FP8
     assert lib.ldit_packed_bytes(C.byref(lt)) == 0 and "multiples of 128" in lib.ldit_last_error().decode()
