@@ -130,13 +130,17 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
     // builds: one HBM-bound pass rounds the batch to a bf16 im2col matrix [B P, 3 p p] (into `big`, free until layer 0) and the
     // bf16 MFMA GEMM multiplies it - 16x the fp32 matrix rate for 1.8 - 4.5 % of those steps (the fp32 kernel took 266 us of
     // the 14.6 ms ViT-L/512 step, 60 us of the 1.6 ms fp8 step).
-    if ((cfg->dtype == LDIT_BF16 || cfg->dtype == LDIT_FP8) && g.Kp % 64 == 0) {
+    if (cfg->dtype != LDIT_F32 && g.Kp % 64 == 0) {
+        // (split-fp32 builds: the im2col rows hold the bf16 planes of the pixels, the GEMM walks the plane products)
+        const int Se = split_planes_of(cfg->dtype) ? split_planes_of(cfg->dtype) : 1;
         char *patches = ws + wm.big;
         LDIT_RUN(probe, LDIT_K_OTHER, launch_patches_rows(static_cast<const float *>(x), patches, batch, g.in_ch, cfg->img_h, cfg->img_w,
-                                                         g.p, stream));
+                                                         g.p, stream, Se));
         GemmExtra xe{};
         xe.pos = F32(pm.pos); xe.patches = g.P;
-        LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(patches, g.Kp, P + pm.patch_w16, F32(pm.patch_b), h, C, batch * g.P, C, g.Kp,
+        if (Se == 2) { xe.nseg = 3; xe.seg_a = 0x001u; xe.seg_w = 0x010u; }
+        if (Se == 3) { xe.nseg = 6; xe.seg_a = 0x001012u; xe.seg_w = 0x010210u; }
+        LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(patches, Se * g.Kp, P + pm.patch_w16, F32(pm.patch_b), h, C, batch * g.P, C, g.Kp,
                                                         EPI_EMBED, nullptr, nullptr, nullptr, xe, stream));
         LDIT_RUN(probe, LDIT_K_OTHER, launch_cls_rows(F32(pm.cls), F32(pm.pos), h, batch, g.T, C, stream));
     } else {
@@ -163,15 +167,14 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
             // fp32 forward on split operands (ldit.h, LDIT_F32X3 / LDIT_F32X6): every GEMM on the bf16 MFMA over the plane products of
             // its operands, fp32 accumulation; LayerNorm, attention (the fp32 kernel), erf-GELU, LayerScale + residual in fp32.
             char *ys = ws + wm.y, *bb = ws + wm.big;
-            float *qkv = reinterpret_cast<float *>(bb), *att = reinterpret_cast<float *>(ws + wm.att);
+            float *qkv = reinterpret_cast<float *>(bb);
             GemmExtra xg = xs;
             xg.nsplit_out = S;
             LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_splitout(h, F32(pl.ln1_w), F32(pl.ln1_b), ys, M, C, cfg->ln_eps, S, stream));
             LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(ys, S * C, P + pl.wqkv, F32(pl.bqkv), qkv, 3 * C, M, 3 * C, C, EPI_F32, nullptr,
                                                             nullptr, nullptr, xs, stream));
             LDIT_RUN(probe, LDIT_K_ATTENTION,
-                     launch_attention(qkv, qkv + C, qkv + 2 * C, att, batch, g.T, g.H, g.D, 3 * C, 3 * C, 3 * C, C, scale, stream));
-            LDIT_RUN(probe, LDIT_K_OTHER, launch_split_planes(att, C, ys, M, C, S, stream));
+                     launch_attention_planes(qkv, qkv + C, qkv + 2 * C, ys, batch, g.T, g.H, g.D, 3 * C, 3 * C, 3 * C, S * C, scale, S, stream));
             LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(ys, S * C, P + pl.wo, F32(pl.bo), h, C, M, C, C, EPI_SCALE_RESID, F32(pl.lam1), h,
                                                             nullptr, xs, stream));
             LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_splitout(h, F32(pl.ln2_w), F32(pl.ln2_b), ys, M, C, cfg->ln_eps, S, stream));
@@ -304,6 +307,9 @@ int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, 
     if (bf16 || fp8) {
         if (!aligned16(w->patch_w)) return fail(LDIT_EINVAL, "weights: patch_w must be 16-byte aligned");
         LDIT_TRY(launch_cvt_bf16(static_cast<const float *>(w->patch_w), P + pm.patch_w16, C * g.Kp, stream));
+    } else if (const int Sp = split_planes_of(cfg->dtype)) {
+        if (!aligned16(w->patch_w)) return fail(LDIT_EINVAL, "weights: patch_w must be 16-byte aligned");
+        LDIT_TRY(launch_split_planes(static_cast<const float *>(w->patch_w), g.Kp, P + pm.patch_w16, (int)C, g.Kp, Sp, stream));
     }
     LDIT_TRY(put(pm.patch_b, w->patch_b, C, "patch_b"));
     LDIT_TRY(put(pm.cls, w->cls, C, "cls"));

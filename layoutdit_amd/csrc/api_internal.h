@@ -1,6 +1,7 @@
 // Host-side internals shared by api.hip (inference entry points) and api_train.hip (train step): geometry checks, the
 // byte layout of the packed parameter block and of the inference workspace, per-launch HIP-event bracketing.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -65,7 +66,8 @@ inline PackedMap packed_map(const Geo &g, int dtype)
     m.patch_b = take(g.C, 4);
     m.cls = take(g.C, 4);
     m.pos = take((size_t)g.T * g.C, 4);
-    m.patch_w16 = (dtype == LDIT_BF16 || dtype == LDIT_FP8) ? take((size_t)g.C * g.Kp, 2) : 0;
+    // bf16 copy of the patch projection (bf16 / fp8 builds) or its bf16 planes (split-fp32 builds): the patch embedding runs on the bf16 GEMM there
+    m.patch_w16 = dtype != LDIT_F32 ? take((size_t)g.C * g.Kp, 2 * (size_t)(split_planes_of(dtype) ? split_planes_of(dtype) : 1)) : 0;
     m.layer.resize(g.L);
     for (int l = 0; l < g.L; ++l) {
         PackedLayer &pl = m.layer[l];
@@ -98,11 +100,11 @@ inline Workspace workspace_map(const Geo &g, int batch, int dtype)
     w.h = take(M * g.C * 4);       // residual stream (always fp32)
     if (const size_t S = (size_t)split_planes_of(dtype)) {
         // split-fp32 builds: y = the S bf16 planes of the LayerNorm / attention output; big = fp32 q|k|v, later the S planes of
-        // the MLP hidden; att = the fp32 attention output before it is split
+        // the MLP hidden
         w.y = take(M * g.C * 2 * S);
-        const size_t qkv = M * 3 * g.C * 4, hid = M * g.F * 2 * S;
-        w.big = take(qkv > hid ? qkv : hid);
-        w.att = take(M * g.C * 4);
+        const size_t qkv = M * 3 * g.C * 4, hid = M * g.F * 2 * S, patches = (size_t)batch * g.P * g.Kp * 2 * S;
+        w.big = take(std::max(std::max(qkv, hid), patches));
+        w.att = 0;
         w.total = o;
         return w;
     }

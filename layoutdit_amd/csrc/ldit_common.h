@@ -225,6 +225,8 @@ int launch_gemm_bf16_tr(const void *A, int lda, bool a_reduction_major, const vo
                         int M, int N, int K, int epi, const GemmExtra &x, hipStream_t stream);
 int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream, float mul = 1.0f);
 // split-fp32 build: dst bf16 [rows, planes * cols] = the `planes` bf16 planes of src fp32 [rows, cols] (row stride lds) side by side
+int launch_attention_planes(const float *Q, const float *K, const float *V, void *O, int B, int N, int H, int D, int ldq,
+                            int ldk, int ldv, int ldo, float scale, int planes, hipStream_t stream);
 int launch_split_planes(const float *src, int lds, void *dst, int rows, int cols, int planes, hipStream_t stream);
 int launch_layernorm_splitout(const float *X, const float *g, const float *b, void *Y, int64_t rows, int C, float eps, int planes,
                               hipStream_t stream);
@@ -279,7 +281,7 @@ int launch_add_inplace(float *a, const float *b, size_t n, hipStream_t stream);
 int launch_expand_rowscale(const float *drop, float *rowscale, int B, int T, int nvec, hipStream_t stream);
 int launch_embed_bwd_small(const float *dh0, float *dpos, float *dcls, float *dpb, int B, int T, int C, hipStream_t stream);
 int launch_patches_transposed(const float *x, void *out, int B, int in_ch, int img_h, int img_w, int p, int Mp, hipStream_t stream);
-int launch_patches_rows(const float *x, void *out, int B, int in_ch, int img_h, int img_w, int p, hipStream_t stream);
+int launch_patches_rows(const float *x, void *out, int B, int in_ch, int img_h, int img_w, int p, hipStream_t stream, int planes = 1);
 int launch_adamw(float *p, const float *g, float *m, float *v, size_t n, float lr, float b1, float b2, float eps, float wd,
                  int step, float grad_scale, void *mirror, hipStream_t stream);
 

@@ -446,15 +446,22 @@ __global__ void __launch_bounds__(256) patches_transposed(const float *__restric
 
 // im2col of the image batch rounded to bf16, ROW-major: out[m][k], m = (b, gy, gx), k = (ch, dy, dx) - the reduction-major W
 // operand of the patch-embedding wgrad.  One workgroup per (b, gy, ch): p image rows of img_w floats -> gw x (p*p) values.
+// planes > 1 (split-fp32 builds): the row holds that many bf16 planes of the pixel side by side (row stride planes * Kp)
 __global__ void __launch_bounds__(256) patches_rows(const float *__restrict__ x, bf16_t *__restrict__ out, int in_ch, int img_h,
-                                                    int img_w, int p, int gw, int gh, int Kp)
+                                                    int img_w, int p, int gw, int gh, int Kp, int planes)
 {
     const int ch = blockIdx.x % in_ch, gy = (blockIdx.x / in_ch) % gh, b = blockIdx.x / (in_ch * gh);
     const float *src = x + (((size_t)b * in_ch + ch) * img_h + (size_t)gy * p) * img_w;
     for (int i = threadIdx.x; i < p * img_w; i += 256) {
         const int dy = i / img_w, xx = i - dy * img_w, gx = xx / p, dx = xx - gx * p;
         const size_t m = ((size_t)b * gh + gy) * gw + gx;
-        out[m * Kp + (ch * p + dy) * p + dx] = (bf16_t)src[i];
+        float v = src[i];
+        bf16_t *d = out + m * ((size_t)planes * Kp) + (ch * p + dy) * p + dx;
+        for (int sp = 0; sp < planes; ++sp) {
+            const bf16_t q = (bf16_t)v;
+            d[(size_t)sp * Kp] = q;
+            v -= (float)q;
+        }
     }
 }
 
@@ -618,11 +625,11 @@ int launch_patches_transposed(const float *x, void *out, int B, int in_ch, int i
     return LDIT_OK;
 }
 
-int launch_patches_rows(const float *x, void *out, int B, int in_ch, int img_h, int img_w, int p, hipStream_t stream)
+int launch_patches_rows(const float *x, void *out, int B, int in_ch, int img_h, int img_w, int p, hipStream_t stream, int planes)
 {
     const int gh = img_h / p, gw = img_w / p;
     LAUNCH_CHECKED(patches_rows, dim3((unsigned)(B * gh * in_ch)), dim3(256), 0, stream, x, static_cast<bf16_t *>(out), in_ch, img_h,
-                   img_w, p, gw, gh, in_ch * p * p);
+                   img_w, p, gw, gh, in_ch * p * p, planes);
     return LDIT_OK;
 }
 

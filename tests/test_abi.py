@@ -156,11 +156,11 @@ def test_low_precision_builds_keep_the_checkpoint_surface_and_size_their_buffers
     assert lib.ldit_packed_bytes(C.byref(lc)) == f32 - 2 * mats + pw16
     lc.dtype = _lib.DTYPE_FP8
     assert lib.ldit_packed_bytes(C.byref(lc)) == f32 - 3 * mats + pw16 + 12 * (32 + 4 * (3 * 768 + 768 + 3072 + 768))   # + scales
-    # split-fp32 builds: every matrix as 2 / 3 bf16 planes (4 / 6 bytes per element), no bf16 patch projection (fp32 embedding)
+    # split-fp32 builds: every matrix as 2 / 3 bf16 planes (4 / 6 bytes per element), + the planes of the patch projection
     lc.dtype = _lib.DTYPE_F32X3
-    assert lib.ldit_packed_bytes(C.byref(lc)) == f32
+    assert lib.ldit_packed_bytes(C.byref(lc)) == f32 + 2 * pw16
     lc.dtype = _lib.DTYPE_F32X6
-    assert lib.ldit_packed_bytes(C.byref(lc)) == f32 + 2 * mats
+    assert lib.ldit_packed_bytes(C.byref(lc)) == f32 + 2 * mats + 3 * pw16
     for dt in (_lib.DTYPE_F32X3, _lib.DTYPE_F32X6):
         lc.dtype = dt
         assert lib.ldit_workspace_bytes(C.byref(lc), 2) > 0
