@@ -223,6 +223,13 @@ int ldit_cast_f32_bf16(const void *src, void *dst, int64_t n, ldit_stream stream
  *   planes * K]: the sum of 3 (planes = 2: x1 w0 + x0 w1 + x0 w0) or 6 (planes = 3: + x2 w0 + x1 w1 + x0 w2) plane products on
  *   v_mfma_f32_32x32x16_bf16, smallest first, ONE fp32 accumulation chain per output element.  K % 64 == 0.  LDIT_EPI_BIAS and
  *   LDIT_EPI_SCALE_RESID write fp32 Y (row stride ldy); LDIT_EPI_BIAS_GELU (exact erf-GELU) writes Y as planes, bf16 [M, planes * N]. */
+/* ldit_attention_planes2: softmax(Q K^T) V per head on two-plane operands (the attention of LDIT_F32X3).  Q, K, V point at plane 0
+ *   of their column slices of a bf16 matrix with row stride ld_in; plane 1 of a row lies plane_in elements further.  Q must
+ *   already be multiplied by scale * log2(e) (ldit_pack_weights folds it into W_q / b_q of that build).  Both products are the
+ *   three plane products p1.q0 + p0.q1 + p0.q0 on the bf16 MFMA, softmax fp32.  O: bf16 [B*N, ldo], plane s of the fp32 result
+ *   at column s * H * D.  D == 64. */
+int ldit_attention_planes2(const void *Q, const void *K, const void *V, void *O, int64_t B, int64_t N, int64_t H, int64_t D,
+                           int64_t ld_in, int64_t plane_in, int64_t ldo, ldit_stream stream);
 int ldit_split_f32_planes(const void *src, int64_t lds, void *dst, int64_t rows, int64_t cols, int32_t planes, ldit_stream stream);
 int ldit_layernorm_f32_planes(const void *X, const void *gamma, const void *beta, void *Y, int64_t rows, int64_t C, float eps,
                               int32_t planes, ldit_stream stream);

@@ -171,10 +171,20 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
             GemmExtra xg = xs;
             xg.nsplit_out = S;
             LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_splitout(h, F32(pl.ln1_w), F32(pl.ln1_b), ys, M, C, cfg->ln_eps, S, stream));
-            LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(ys, S * C, P + pl.wqkv, F32(pl.bqkv), qkv, 3 * C, M, 3 * C, C, EPI_F32, nullptr,
-                                                            nullptr, nullptr, xs, stream));
-            LDIT_RUN(probe, LDIT_K_ATTENTION,
-                     launch_attention_planes(qkv, qkv + C, qkv + 2 * C, ys, batch, g.T, g.H, g.D, 3 * C, 3 * C, 3 * C, S * C, scale, S, stream));
+            if (S == 2) {
+                // f32x3: q|k|v leave their GEMM as bf16 planes [M, 2 * 3C] (q pre-multiplied by scale log2 e at pack time) and the
+                // attention runs on the plane products too (attention_planes.hip)
+                const __bf16 *qp = reinterpret_cast<const __bf16 *>(bb);
+                LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(ys, S * C, P + pl.wqkv, F32(pl.bqkv), bb, S * 3 * C, M, 3 * C, C, EPI_BIAS_SPLIT,
+                                                                nullptr, nullptr, nullptr, xg, stream));
+                LDIT_RUN(probe, LDIT_K_ATTENTION,
+                         launch_attention_planes2(qp, qp + C, qp + 2 * C, ys, batch, g.T, g.H, g.D, S * 3 * C, 3 * C, S * C, stream));
+            } else {
+                LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(ys, S * C, P + pl.wqkv, F32(pl.bqkv), qkv, 3 * C, M, 3 * C, C, EPI_F32, nullptr,
+                                                                nullptr, nullptr, xs, stream));
+                LDIT_RUN(probe, LDIT_K_ATTENTION,
+                         launch_attention_planes(qkv, qkv + C, qkv + 2 * C, ys, batch, g.T, g.H, g.D, 3 * C, 3 * C, 3 * C, S * C, scale, S, stream));
+            }
             LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(ys, S * C, P + pl.wo, F32(pl.bo), h, C, M, C, C, EPI_SCALE_RESID, F32(pl.lam1), h,
                                                             nullptr, xs, stream));
             LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_splitout(h, F32(pl.ln2_w), F32(pl.ln2_b), ys, M, C, cfg->ln_eps, S, stream));
@@ -292,7 +302,7 @@ int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, 
         if (const int Sp = split_planes_of(cfg->dtype)) {
             // split-fp32 builds: the matrix as Sp bf16 planes side by side per row; `elt_off` counts fp32 elements of whole rows
             if (!aligned16(src)) return fail(LDIT_EINVAL, "weights: %s must be 16-byte aligned", what);
-            return launch_split_planes(static_cast<const float *>(src), (int)cols, P + off + elt_off * 2 * Sp, (int)rows, (int)cols, Sp, stream);
+            return launch_split_planes(static_cast<const float *>(src), (int)cols, P + off + elt_off * 2 * Sp, (int)rows, (int)cols, Sp, stream, mul);
         }
         if (!bf16 && !fp8) return put(off + elt_off * 4, src, rows * cols, what);
         if (!aligned16(src)) return fail(LDIT_EINVAL, "weights: %s must be 16-byte aligned", what);
@@ -301,7 +311,8 @@ int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, 
                                          reinterpret_cast<float *>(P + sw_off) + row0, (int)rows, (int)cols, stream, mul);
         return launch_cvt_bf16(static_cast<const float *>(src), P + off + elt_off * 2, rows * cols, stream, mul);
     };
-    const float qfold = (bf16 || fp8) ? (1.0f / sqrtf((float)g.D)) * 1.44269504088896340736f : 1.0f;
+    // (f32x3 too: its attention runs on bf16-plane operands with exp2-domain scores, attention_planes.hip)
+    const float qfold = (bf16 || fp8 || cfg->dtype == LDIT_F32X3) ? (1.0f / sqrtf((float)g.D)) * 1.44269504088896340736f : 1.0f;
     const size_t C = g.C, F = g.F;
     LDIT_TRY(put(pm.patch_w, w->patch_w, C * g.Kp, "patch_w"));
     if (bf16 || fp8) {
@@ -437,6 +448,16 @@ int ldit_embed_f32(const void *x, const void *patch_w, const void *patch_b, cons
     return embed(g, static_cast<const float *>(x), static_cast<const float *>(patch_w), static_cast<const float *>(patch_b),
                  static_cast<const float *>(cls), static_cast<const float *>(pos), static_cast<float *>(out), (int)B,
                  (int)img_h, (int)img_w, static_cast<hipStream_t>(stream), probe);
+}
+
+int ldit_attention_planes2(const void *Q, const void *K, const void *V, void *O, int64_t B, int64_t N, int64_t H, int64_t D,
+                           int64_t ld_in, int64_t plane_in, int64_t ldo, ldit_stream stream)
+{
+    if (B <= 0 || N <= 0 || H <= 0) return fail(LDIT_EINVAL, "attention_planes: empty problem");
+    if (B * N * (ld_in > ldo ? ld_in : ldo) >= (1ll << 31) || B * H * ((N + 127) / 128) >= (1ll << 31))
+        return fail(LDIT_EUNSUPPORTED, "attention_planes: operand exceeds 2^31 elements");
+    return launch_attention_planes2(Q, K, V, O, (int)B, (int)N, (int)H, (int)D, (int)ld_in, (int)plane_in, (int)ldo,
+                                    static_cast<hipStream_t>(stream));
 }
 
 int ldit_split_f32_planes(const void *src, int64_t lds, void *dst, int64_t rows, int64_t cols, int32_t planes, ldit_stream stream)

@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
     if (cols_in && m0 + BM <= p.M && !p.direct_epi) {
         __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
-        store_rows_via_lds<TM, TN, EPI, f32_out<EPI>() ? EPI_OUT_F32 : EPI == EPI_GELU_SPLIT ? EPI_OUT_SPLIT : EPI_OUT_BF16>(
+        store_rows_via_lds<TM, TN, EPI, f32_out<EPI>() ? EPI_OUT_F32 : (EPI == EPI_GELU_SPLIT || EPI == EPI_BIAS_SPLIT) ? EPI_OUT_SPLIT : EPI_OUT_BF16>(
             acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, nullptr, p.ldy, mw, nw, lane, 1.0f, 1.0f, p.x);
     } else if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
     else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
@@ -364,7 +364,7 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
     // workgroups per CU, a barrier-phased ping-pong of the two waves per SIMD, a v_mfma_f32_16x16x32_bf16 build and a
     // four-wave 256 x 256 tile - none beat this kernel on any shape; the 256 x 128 tile stays selectable for experiments.
     // (EPI_EMBED and EPI_F32 priced like the residual epilogue, EPI_GELU_BWD like the GELU one)
-    const double a256[7] = {19.0, 18.5, 25.0, 25.0, 25.0, 18.5, 25.0}, r128[7] = {5.2, 5.0, 7.7, 7.7, 7.7, 5.0, 7.7};
+    const double a256[8] = {19.0, 18.5, 25.0, 25.0, 25.0, 18.5, 25.0, 25.0}, r128[8] = {5.2, 5.0, 7.7, 7.7, 7.7, 5.0, 7.7, 7.7};
     const long sp = a.x.splits;
     const int depth = a.x.nseg > 1 ? a.K * a.x.nseg : a.K;     // k-depth of one output element (all plane segments)
     const long t256 = sp * ((a.M + 255) / 256) * ((a.N + 255) / 256), t128 = sp * ((a.M + 127) / 128) * ((a.N + 127) / 128);
@@ -410,13 +410,16 @@ __global__ void __launch_bounds__(256) cvt_f32_bf16(const float *__restrict__ sr
 
 // fp32 [rows, cols] (row stride lds) -> `S` bf16 planes side by side, [rows, S * cols]: x ~= p0 + p1 (+ p2).  4 elements per thread.
 template <int S>
-__global__ void __launch_bounds__(256) split_planes(const float *__restrict__ src, int lds, bf16_t *__restrict__ dst, int rows, int cols)
+__global__ void __launch_bounds__(256) split_planes(const float *__restrict__ src, int lds, bf16_t *__restrict__ dst, int rows, int cols,
+                                                    float mul)
 {
     const int c4 = cols >> 2;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)rows * c4) return;
     const int r = (int)(i / c4), c = (int)(i - (size_t)r * c4) * 4;
     f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)r * lds + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= mul;         // pack-time factor (1, or scale * log2 e on W_q): rounded once, then split
     bf16_t *d = dst + (size_t)r * (S * cols) + c;
 #pragma unroll
     for (int sp = 0; sp < S; ++sp) {
@@ -429,14 +432,14 @@ __global__ void __launch_bounds__(256) split_planes(const float *__restrict__ sr
 
 }  // namespace
 
-int launch_split_planes(const float *src, int lds, void *dst, int rows, int cols, int planes, hipStream_t stream)
+int launch_split_planes(const float *src, int lds, void *dst, int rows, int cols, int planes, hipStream_t stream, float mul)
 {
     if (rows <= 0 || cols <= 0) return LDIT_OK;
     if (!src || !dst || (cols & 3) || (lds & 3) || lds < cols || !aligned16(src) || (reinterpret_cast<uintptr_t>(dst) & 7u))
         return fail(LDIT_EINVAL, "split_planes: null / misaligned operand or cols not a multiple of 4");
     const unsigned blocks = (unsigned)(((size_t)rows * (cols >> 2) + 255) / 256);
-    if (planes == 2) hipLaunchKernelGGL(split_planes<2>, dim3(blocks), dim3(256), 0, stream, src, lds, static_cast<bf16_t *>(dst), rows, cols);
-    else if (planes == 3) hipLaunchKernelGGL(split_planes<3>, dim3(blocks), dim3(256), 0, stream, src, lds, static_cast<bf16_t *>(dst), rows, cols);
+    if (planes == 2) hipLaunchKernelGGL(split_planes<2>, dim3(blocks), dim3(256), 0, stream, src, lds, static_cast<bf16_t *>(dst), rows, cols, mul);
+    else if (planes == 3) hipLaunchKernelGGL(split_planes<3>, dim3(blocks), dim3(256), 0, stream, src, lds, static_cast<bf16_t *>(dst), rows, cols, mul);
     else return fail(LDIT_EINVAL, "split_planes: %d planes (2 or 3)", planes);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
@@ -518,6 +521,10 @@ static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const flo
             if (x.nsplit_out < 2 || x.nsplit_out > 3 || ldy != x.nsplit_out * N || (N & 3))
                 return fail(LDIT_EINVAL, "gemm_bf16: split GELU epilogue needs 2 or 3 output planes and ldy = planes * N");
             return launch_h_tiled<EPI_GELU_SPLIT>(a, stream);
+        case EPI_BIAS_SPLIT:
+            if (x.nsplit_out < 2 || x.nsplit_out > 3 || ldy != x.nsplit_out * N || (N & 3))
+                return fail(LDIT_EINVAL, "gemm_bf16: split bias epilogue needs 2 or 3 output planes and ldy = planes * N");
+            return launch_h_tiled<EPI_BIAS_SPLIT>(a, stream);
         case EPI_EMBED:
             if (!x.pos || x.patches <= 0 || M % x.patches || !aligned16(x.pos) || (ldy & 3))
                 return fail(LDIT_EINVAL, "gemm_bf16: patch-embedding epilogue needs pos, patches | M and 16-byte rows");

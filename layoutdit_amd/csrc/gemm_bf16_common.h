@@ -141,7 +141,7 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
                         for (int e = 0; e < 4; ++e)
                             if (n + e < p.N) { y[o + e] = v[e]; if (dual) p.Y2[o + e] = v[e]; }
                     }
-                } else if (EPI == EPI_GELU_SPLIT) {
+                } else if (EPI == EPI_GELU_SPLIT || EPI == EPI_BIAS_SPLIT) {
                     bf16_t *y = static_cast<bf16_t *>(p.Y);
                     const unsigned plane = (unsigned)p.ldy / (unsigned)p.x.nsplit_out;
                     f32x4 r = v;

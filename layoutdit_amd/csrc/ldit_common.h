@@ -130,7 +130,8 @@ enum AMode { A_ROWMAJOR = 0, A_PATCH = 1,
 enum Epi { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_SCALE_RESID = 2, EPI_EMBED = 3,
            EPI_F32 = 4,        // bf16 GEMM only: Y fp32 = acc (+ bias); dgrad into LayerNorm backward, wgrad slabs
            EPI_GELU_BWD = 5,   // bf16 GEMM only: Y bf16 = acc * aux, aux = gelu'(pre-activation) saved by the forward
-           EPI_GELU_SPLIT = 6 }; // bf16 GEMM, split-fp32 build only: Y = split_bf16(gelu_erf(acc + bias)), `nsplit_out` bf16 planes per row
+           EPI_GELU_SPLIT = 6, // bf16 GEMM, split-fp32 build only: Y = split_bf16(gelu_erf(acc + bias)), `nsplit_out` bf16 planes per row
+           EPI_BIAS_SPLIT = 7 }; // the same without the GELU (q|k|v of the split-fp32 build, consumed as planes by attention_planes)
 
 // Optional operands of the bf16 GEMM used by the train step (training.hip); all null / 1 for inference.
 struct GemmExtra {
@@ -227,7 +228,10 @@ int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream, f
 // split-fp32 build: dst bf16 [rows, planes * cols] = the `planes` bf16 planes of src fp32 [rows, cols] (row stride lds) side by side
 int launch_attention_planes(const float *Q, const float *K, const float *V, void *O, int B, int N, int H, int D, int ldq,
                             int ldk, int ldv, int ldo, float scale, int planes, hipStream_t stream);
-int launch_split_planes(const float *src, int lds, void *dst, int rows, int cols, int planes, hipStream_t stream);
+int launch_split_planes(const float *src, int lds, void *dst, int rows, int cols, int planes, hipStream_t stream, float mul = 1.0f);
+// f32x3 build: attention on bf16-plane operands (attention_planes.hip); queries pre-multiplied by scale * log2(e)
+int launch_attention_planes2(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ld_in, int plane_in,
+                             int ldo, hipStream_t stream);
 int launch_layernorm_splitout(const float *X, const float *g, const float *b, void *Y, int64_t rows, int C, float eps, int planes,
                               hipStream_t stream);
 // fp8: the per-tensor part of the accumulator's dequantisation is d_act[0] when d_act is non-null (device), else the host
