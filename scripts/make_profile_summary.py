@@ -36,7 +36,8 @@ with open(os.path.join(p, f"{out}_pmc_summary.txt"), "w") as f:
 
 
 dtype = key.split(":")[-1]
-FAMILY = {"f32": ("gemm_panel_f32", "gemm_f32_mfma", "gemm_thin_f32"), "bf16": ("gemm_bf16",), "fp8": ("gemm_fp8",)}[dtype]
+FAMILY = {"f32": ("gemm_panel_f32", "gemm_f32_mfma", "gemm_thin_f32"), "bf16": ("gemm_bf16",), "fp8": ("gemm_fp8",),
+          "f32x3": ("gemm_bf16",), "f32x6": ("gemm_bf16",)}[dtype]      # split-fp32 builds: their GEMMs ARE the bf16 kernels
 
 
 def in_family(name: str) -> bool:
