@@ -180,7 +180,7 @@ def test_fp8_forward_micro_vs_oracle():
         r = hidden[t]
         h = out.hidden_states[t].cpu().numpy()
         assert np.isfinite(h).all()
-        assert rel_l2(h, r) < (1e-5 if t == 0 else 1e-1), t          # tap 0 is the fp32 embedding
+        assert rel_l2(h, r) < (1e-2 if t == 0 else 1e-1), t          # tap 0 is the embedding: bf16 MFMA operands, fp32 accumulate (measured 1.8e-3)
         assert _cos(h, r) > 0.995, t
 
 
