@@ -49,11 +49,11 @@ enum ldit_dtype {
                       ldit_set_fp8_act_scales (calibration is the caller's job) */
     LDIT_F32X3 = 4, /* fp32 forward with every GEMM operand held as TWO bf16 planes x ~= p0 + p1 (p0 = bf16(x), p1 = bf16(x - p0):
                       16 significant bits) and every product computed as p1.q0 + p0.q1 + p0.q0 on the bf16 MFMA (16x the fp32
-                      matrix rate) with fp32 accumulation - "bf16x3".  Residual stream, LayerNorm, attention (the fp32 kernel), erf-GELU,
-                      biases and taps are fp32 exactly as in LDIT_F32.  Whole-path error vs float64: 3 - 5e-6 relative L2 (LDIT_F32:
-                      5e-7), i.e. inside the fp32 build's own parity gates (2e-5) and 200x inside the north-star 1e-3. */
+                      matrix rate) with fp32 accumulation - "bf16x3" -, the two products of the attention included.  Residual stream, LayerNorm,
+                      softmax, erf-GELU, biases and taps are fp32 exactly as in LDIT_F32.  Whole-path error vs float64: 4.4 - 5.6e-6
+                      relative L2 (LDIT_F32: 7 - 9e-7), i.e. inside the fp32 build's own parity gates (2e-5), 180x inside the north-star 1e-3. */
     LDIT_F32X6 = 5  /* the same with THREE planes (24 significant bits) and the six plane products down to 2^-24: fp32-grade error
-                      (5e-7 vs float64, that of the fp32 MFMA path and of ATen's CPU fp32 GEMMs) at 6 bf16 MFMAs per product */
+                      (6 - 8e-7 vs float64: under the fp32 MFMA path's on every tap, at that of ATen's CPU fp32 forward) at 6 bf16 MFMAs per product */
 };
 
 /* order of the per-layer activation scales handed to ldit_set_fp8_act_scales (scale = amax / 448) */
@@ -221,15 +221,15 @@ int ldit_cast_f32_bf16(const void *src, void *dst, int64_t n, ldit_stream stream
  * ldit_layernorm_f32_planes: ldit_layernorm_f32 with the result written as such planes, Y bf16 [rows, planes * C].
  * ldit_linear_planes: Y = epilogue(X . W^T) for fp32 X [M,K] and W [N,K] given as planes Xp [M, planes * K] (row stride lda), Wp [N,
  *   planes * K]: the sum of 3 (planes = 2: x1 w0 + x0 w1 + x0 w0) or 6 (planes = 3: + x2 w0 + x1 w1 + x0 w2) plane products on
- *   v_mfma_f32_32x32x16_bf16, smallest first, ONE fp32 accumulation chain per output element.  K % 64 == 0.  LDIT_EPI_BIAS and
+ *   v_mfma_f32_32x32x16_bf16 - per 64-deep k-tile, smallest first -, ONE fp32 accumulation chain per output element.  K % 64 == 0.  LDIT_EPI_BIAS and
  *   LDIT_EPI_SCALE_RESID write fp32 Y (row stride ldy); LDIT_EPI_BIAS_GELU (exact erf-GELU) writes Y as planes, bf16 [M, planes * N]. */
-/* ldit_attention_planes2: softmax(Q K^T) V per head on two-plane operands (the attention of LDIT_F32X3).  Q, K, V point at plane 0
- *   of their column slices of a bf16 matrix with row stride ld_in; plane 1 of a row lies plane_in elements further.  Q must
- *   already be multiplied by scale * log2(e) (ldit_pack_weights folds it into W_q / b_q of that build).  Both products are the
- *   three plane products p1.q0 + p0.q1 + p0.q0 on the bf16 MFMA, softmax fp32.  O: bf16 [B*N, ldo], plane s of the fp32 result
- *   at column s * H * D.  D == 64. */
-int ldit_attention_planes2(const void *Q, const void *K, const void *V, void *O, int64_t B, int64_t N, int64_t H, int64_t D,
-                           int64_t ld_in, int64_t plane_in, int64_t ldo, ldit_stream stream);
+/* ldit_attention_planes: softmax(Q K^T) V per head on plane operands (the attention of LDIT_F32X3 / LDIT_F32X6; planes = 2 / 3).  Q, K, V
+ *   point at plane 0 of their column slices of a bf16 matrix with row stride ld_in; plane s of a row lies s * plane_in elements
+ *   further.  Q must already be multiplied by scale * log2(e) (ldit_pack_weights folds it into W_q / b_q of those builds).  Both
+ *   products are the 3 / 6 plane products of ldit_linear_planes on the bf16 MFMA, softmax fp32.  O: bf16 [B*N, ldo], plane s of the
+ *   fp32 result at column s * H * D.  D == 64. */
+int ldit_attention_planes(const void *Q, const void *K, const void *V, void *O, int64_t B, int64_t N, int64_t H, int64_t D,
+                          int64_t ld_in, int64_t plane_in, int64_t ldo, int32_t planes, ldit_stream stream);
 int ldit_split_f32_planes(const void *src, int64_t lds, void *dst, int64_t rows, int64_t cols, int32_t planes, ldit_stream stream);
 int ldit_layernorm_f32_planes(const void *X, const void *gamma, const void *beta, void *Y, int64_t rows, int64_t C, float eps,
                               int32_t planes, ldit_stream stream);

@@ -57,7 +57,7 @@ SIGNATURES = {
     "ldit_layernorm_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp]),
     "ldit_attention_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ldit_embed_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
-    "ldit_attention_planes2": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "ldit_attention_planes": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "ldit_split_f32_planes": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "ldit_layernorm_f32_planes": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, C.c_float, _i32, _vp]),
     "ldit_linear_planes": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _vp]),

@@ -50,6 +50,8 @@ DiagSwitches read_switches()
     d.fp8_noskinny = is("LDIT_GEMM_FP8_NOSKINNY", '1');
     d.direct_epi = is("LDIT_GEMM_DIRECT_EPILOGUE", '1');
     d.attn_bf16_kt4 = is("LDIT_ATTN_BF16_KT", '4');
+    d.seg_order = digit("LDIT_GEMM_SEG_ORDER", 0, 1);
+    d.attn_bf16_nw = digit("LDIT_ATTN_BF16_NW", 4, 8);
     return d;
 }
 DiagSwitches &switches()
@@ -140,6 +142,7 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
         xe.pos = F32(pm.pos); xe.patches = g.P;
         if (Se == 2) { xe.nseg = 3; xe.seg_a = 0x001u; xe.seg_w = 0x010u; }
         if (Se == 3) { xe.nseg = 6; xe.seg_a = 0x001012u; xe.seg_w = 0x010210u; }
+        xe.seg_inner = 1;
         LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(patches, Se * g.Kp, P + pm.patch_w16, F32(pm.patch_b), h, C, batch * g.P, C, g.Kp,
                                                         EPI_EMBED, nullptr, nullptr, nullptr, xe, stream));
         LDIT_RUN(probe, LDIT_K_OTHER, launch_cls_rows(F32(pm.cls), F32(pm.pos), h, batch, g.T, C, stream));
@@ -160,6 +163,9 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
     GemmExtra xs{};
     if (S == 2) { xs.nseg = 3; xs.seg_a = 0x001u; xs.seg_w = 0x010u; }
     if (S == 3) { xs.nseg = 6; xs.seg_a = 0x001012u; xs.seg_w = 0x010210u; }
+    // per 64-deep k-tile (k-tile outermost): the operand tiles one product has just pulled through L2 serve the next one - 1-5 % on the
+    // q|k|v and fc1 GEMMs against whole-K segments (profiles/r03_planes_segment_order.txt), never slower
+    xs.seg_inner = 1;
     for (int l = 0; l < g.L; ++l) {
         const PackedLayer &pl = pm.layer[l];
         float *tap = tap_for(l + 1);
@@ -167,23 +173,18 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
             // fp32 forward on split operands (ldit.h, LDIT_F32X3 / LDIT_F32X6): every GEMM on the bf16 MFMA over the plane products of
             // its operands, fp32 accumulation; LayerNorm, attention (the fp32 kernel), erf-GELU, LayerScale + residual in fp32.
             char *ys = ws + wm.y, *bb = ws + wm.big;
-            float *qkv = reinterpret_cast<float *>(bb);
             GemmExtra xg = xs;
             xg.nsplit_out = S;
             LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_splitout(h, F32(pl.ln1_w), F32(pl.ln1_b), ys, M, C, cfg->ln_eps, S, stream));
-            if (S == 2) {
-                // f32x3: q|k|v leave their GEMM as bf16 planes [M, 2 * 3C] (q pre-multiplied by scale log2 e at pack time) and the
-                // attention runs on the plane products too (attention_planes.hip)
+            {
+                // q|k|v leave their GEMM as bf16 planes [M, S * 3C] (q pre-multiplied by scale log2 e at pack time) and the attention
+                // runs on the plane products too (attention_planes.hip: 3 products for two planes, 6 for three)
                 const __bf16 *qp = reinterpret_cast<const __bf16 *>(bb);
                 LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(ys, S * C, P + pl.wqkv, F32(pl.bqkv), bb, S * 3 * C, M, 3 * C, C, EPI_BIAS_SPLIT,
                                                                 nullptr, nullptr, nullptr, xg, stream));
                 LDIT_RUN(probe, LDIT_K_ATTENTION,
-                         launch_attention_planes2(qp, qp + C, qp + 2 * C, ys, batch, g.T, g.H, g.D, S * 3 * C, 3 * C, S * C, stream));
-            } else {
-                LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(ys, S * C, P + pl.wqkv, F32(pl.bqkv), qkv, 3 * C, M, 3 * C, C, EPI_F32, nullptr,
-                                                                nullptr, nullptr, xs, stream));
-                LDIT_RUN(probe, LDIT_K_ATTENTION,
-                         launch_attention_planes(qkv, qkv + C, qkv + 2 * C, ys, batch, g.T, g.H, g.D, 3 * C, 3 * C, 3 * C, S * C, scale, S, stream));
+                         (S == 2 ? launch_attention_planes2 : launch_attention_planes3)(qp, qp + C, qp + 2 * C, ys, batch, g.T, g.H, g.D,
+                                                                                        S * 3 * C, 3 * C, S * C, stream));
             }
             LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_ex(ys, S * C, P + pl.wo, F32(pl.bo), h, C, M, C, C, EPI_SCALE_RESID, F32(pl.lam1), h,
                                                             nullptr, xs, stream));
@@ -311,8 +312,8 @@ int ldit_pack_weights(const ldit_cfg *cfg, const ldit_weights *w, void *packed, 
                                          reinterpret_cast<float *>(P + sw_off) + row0, (int)rows, (int)cols, stream, mul);
         return launch_cvt_bf16(static_cast<const float *>(src), P + off + elt_off * 2, rows * cols, stream, mul);
     };
-    // (f32x3 too: its attention runs on bf16-plane operands with exp2-domain scores, attention_planes.hip)
-    const float qfold = (bf16 || fp8 || cfg->dtype == LDIT_F32X3) ? (1.0f / sqrtf((float)g.D)) * 1.44269504088896340736f : 1.0f;
+    // (the split-fp32 builds too: their attention runs on bf16-plane operands with exp2-domain scores, attention_planes.hip)
+    const float qfold = (bf16 || fp8 || split_planes_of(cfg->dtype)) ? (1.0f / sqrtf((float)g.D)) * 1.44269504088896340736f : 1.0f;
     const size_t C = g.C, F = g.F;
     LDIT_TRY(put(pm.patch_w, w->patch_w, C * g.Kp, "patch_w"));
     if (bf16 || fp8) {
@@ -450,14 +451,15 @@ int ldit_embed_f32(const void *x, const void *patch_w, const void *patch_b, cons
                  (int)img_h, (int)img_w, static_cast<hipStream_t>(stream), probe);
 }
 
-int ldit_attention_planes2(const void *Q, const void *K, const void *V, void *O, int64_t B, int64_t N, int64_t H, int64_t D,
-                           int64_t ld_in, int64_t plane_in, int64_t ldo, ldit_stream stream)
+int ldit_attention_planes(const void *Q, const void *K, const void *V, void *O, int64_t B, int64_t N, int64_t H, int64_t D,
+                          int64_t ld_in, int64_t plane_in, int64_t ldo, int32_t planes, ldit_stream stream)
 {
+    if (planes != 2 && planes != 3) return fail(LDIT_EINVAL, "attention_planes: %d planes (2 or 3)", planes);
     if (B <= 0 || N <= 0 || H <= 0) return fail(LDIT_EINVAL, "attention_planes: empty problem");
     if (B * N * (ld_in > ldo ? ld_in : ldo) >= (1ll << 31) || B * H * ((N + 127) / 128) >= (1ll << 31))
         return fail(LDIT_EUNSUPPORTED, "attention_planes: operand exceeds 2^31 elements");
-    return launch_attention_planes2(Q, K, V, O, (int)B, (int)N, (int)H, (int)D, (int)ld_in, (int)plane_in, (int)ldo,
-                                    static_cast<hipStream_t>(stream));
+    return (planes == 2 ? launch_attention_planes2 : launch_attention_planes3)(Q, K, V, O, (int)B, (int)N, (int)H, (int)D, (int)ld_in,
+                                                                              (int)plane_in, (int)ldo, static_cast<hipStream_t>(stream));
 }
 
 int ldit_split_f32_planes(const void *src, int64_t lds, void *dst, int64_t rows, int64_t cols, int32_t planes, ldit_stream stream)
@@ -485,6 +487,7 @@ int ldit_linear_planes(const void *Xp, int64_t lda, const void *Wp, const void *
     GemmExtra x{};
     if (planes == 2) { x.nseg = 3; x.seg_a = 0x001u; x.seg_w = 0x010u; }
     else { x.nseg = 6; x.seg_a = 0x001012u; x.seg_w = 0x010210u; }
+    x.seg_inner = 1;
     int epi;
     if (epilogue == LDIT_EPI_BIAS) epi = EPI_F32;
     else if (epilogue == LDIT_EPI_SCALE_RESID) epi = EPI_SCALE_RESID;

@@ -401,7 +401,9 @@ static int launch_attn(const void *Q, const void *K, const void *V, void *O, int
     // scale == 0: Q is pre-multiplied by scale * log2(e) (PRE, the packed inference path); otherwise the factor is applied here.
     static std::atomic<unsigned long long> set2{0}, set4{0}, set2p{0};      // per-device bookkeeping (ensure_dynamic_lds)
     // (eight query tiles per workgroup - half the DMA pieces and K/V traffic per tile - measured equal: 108.6 vs 107.8 us at N = 1025)
-    if (scale == 0.0f) LDIT_TRY_RC(go(attention_bf16<2, NW, OUT_FP8, true>, 2 * 2 * 2 * 32 * KROWB, set2p));
+    static std::atomic<unsigned long long> set2p8{0};
+    if (scale == 0.0f && diag().attn_bf16_nw == 8) LDIT_TRY_RC(go_nw(attention_bf16<2, 8, OUT_FP8, true>, 8, 2 * 2 * 2 * 32 * KROWB, set2p8));
+    else if (scale == 0.0f) LDIT_TRY_RC(go(attention_bf16<2, NW, OUT_FP8, true>, 2 * 2 * 2 * 32 * KROWB, set2p));
     else if (kt4) LDIT_TRY_RC(go(attention_bf16<4, NW, OUT_FP8, false>, 2 * 2 * 4 * 32 * KROWB, set4));
     else LDIT_TRY_RC(go(attention_bf16<2, NW, OUT_FP8, false>, 2 * 2 * 2 * 32 * KROWB, set2));
     LDIT_HIP_CHECK(hipGetLastError());

@@ -36,12 +36,9 @@ constexpr int VSTR = 64;
 
 // (NW = 4 is held to the 256 registers of NW = 8: given 512, hipcc parks every V fragment read right in front of its MFMA
 // and the P V phase ran 2.7x longer - 42.8k vs 15.9k cycles per wave.)
-// SPL = 0: O fp32 [B N, ldo].  SPL = 2 / 3 (split-fp32 builds): O is written as that many bf16 planes o ~= p0 + p1 (+ p2), plane s at
-// column s * H * 64 of a bf16 row of ldo elements - the operand of the o_proj GEMM, without an fp32 round trip through HBM.
-typedef __bf16 att_bf16x4 __attribute__((ext_vector_type(4)));
-template <int KT, int NW, int SPL>
+template <int KT, int NW>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : NW / 4) attention_f32(const float *__restrict__ Q, const float *__restrict__ K,
-                                                     const float *__restrict__ V, void *__restrict__ Ov, int N, int H,
+                                                     const float *__restrict__ V, float *__restrict__ O, int N, int H,
                                                      int ldq, int ldk, int ldv, int ldo, float scale, int nqg)
 {
     constexpr int KROWS = KT * 32;
@@ -211,8 +208,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : NW / 4) attention_f32(c
     const float l = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l;
     const int qrow = qt * 32 + li;
-    if (qrow < N && SPL == 0) {
-        float *op = static_cast<float *>(Ov) + (tok0 + qrow) * ldo + head * 64 + 4 * lh;
+    if (qrow < N) {
+        float *op = O + (tok0 + qrow) * ldo + head * 64 + 4 * lh;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -220,30 +217,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : NW / 4) attention_f32(c
                 f32x4 t = {o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
                 *reinterpret_cast<f32x4 *>(op + dt * 32 + 8 * g) = t;
             }
-    } else if (qrow < N) {
-        __bf16 *op = static_cast<__bf16 *>(Ov) + (tok0 + qrow) * ldo + head * 64 + 4 * lh;
-        const int plane = H * 64;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 t = {o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
-#pragma unroll
-                for (int sp = 0; sp < (SPL ? SPL : 1); ++sp) {
-                    const att_bf16x4 pk = {(__bf16)t[0], (__bf16)t[1], (__bf16)t[2], (__bf16)t[3]};
-                    *reinterpret_cast<att_bf16x4 *>(op + sp * plane + dt * 32 + 8 * g) = pk;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] -= (float)pk[e];
-                }
-            }
     }
 }
 
 }  // namespace
 
-template <int SPL>
-static int launch_attention_t(const float *Q, const float *K, const float *V, void *O, int B, int N, int H, int D, int ldq,
-                              int ldk, int ldv, int ldo, float scale, hipStream_t stream)
+int launch_attention(const float *Q, const float *K, const float *V, float *O, int B, int N, int H, int D, int ldq,
+                     int ldk, int ldv, int ldo, float scale, hipStream_t stream)
 {
     if (B <= 0 || N <= 0 || H <= 0) return fail(LDIT_EINVAL, "attention: empty problem");
     if (D != 64) return fail(LDIT_EUNSUPPORTED, "attention: head_dim=%d, only 64 is implemented", D);
@@ -267,26 +247,10 @@ static int launch_attention_t(const float *Q, const float *K, const float *V, vo
     // does not depend on which workgroup computes it, so the results are bit-identical either way.
     static std::atomic<unsigned long long> set8{0}, set4{0};      // per-device bookkeeping (ensure_dynamic_lds)
     const long wgs8 = (long)B * H * ((nqt + 7) / 8);
-    if (wgs8 <= 128 && nqt > 4) { if (int rc = go(attention_f32<KT, 4, SPL>, 4, set4)) return rc; }
-    else if (int rc = go(attention_f32<KT, 8, SPL>, 8, set8)) return rc;
+    if (wgs8 <= 128 && nqt > 4) { if (int rc = go(attention_f32<KT, 4>, 4, set4)) return rc; }
+    else if (int rc = go(attention_f32<KT, 8>, 8, set8)) return rc;
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
-}
-
-int launch_attention(const float *Q, const float *K, const float *V, float *O, int B, int N, int H, int D, int ldq,
-                     int ldk, int ldv, int ldo, float scale, hipStream_t stream)
-{
-    return launch_attention_t<0>(Q, K, V, O, B, N, H, D, ldq, ldk, ldv, ldo, scale, stream);
-}
-
-// split-fp32 builds: the output as `planes` bf16 planes per row, O bf16 [B N, ldo], ldo >= planes * H * 64
-int launch_attention_planes(const float *Q, const float *K, const float *V, void *O, int B, int N, int H, int D, int ldq,
-                            int ldk, int ldv, int ldo, float scale, int planes, hipStream_t stream)
-{
-    if (ldo < planes * H * 64) return fail(LDIT_EINVAL, "attention: output row too short for %d planes", planes);
-    if (planes == 2) return launch_attention_t<2>(Q, K, V, O, B, N, H, D, ldq, ldk, ldv, ldo, scale, stream);
-    if (planes == 3) return launch_attention_t<3>(Q, K, V, O, B, N, H, D, ldq, ldk, ldv, ldo, scale, stream);
-    return fail(LDIT_EINVAL, "attention: %d output planes (2 or 3)", planes);
 }
 
 }  // namespace ldit

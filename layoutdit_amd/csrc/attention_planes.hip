@@ -1,6 +1,7 @@
-// Fused multi-head self-attention of the split-fp32 build "f32x3" (include/ldit.h, LDIT_F32X3):  O = softmax(Q K^T * scale) V per
-// (image, head), every operand of both products held as TWO bf16 planes x ~= p0 + p1 (16 significant bits) and every product
-// formed as p1.q0 + p0.q1 + p0.q0 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; softmax fp32.  D = 64, any N.
+// Fused multi-head self-attention of the split-fp32 builds (include/ldit.h, LDIT_F32X3 / LDIT_F32X6):  O = softmax(Q K^T * scale) V per
+// (image, head), every operand of both products held as TWO (THREE) bf16 planes x ~= p0 + p1 (+ p2) and every product formed from
+// three (six) plane products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; softmax fp32.  D = 64, any N.  Described for two
+// planes below; three planes = the same kernel with six products and 96 KB of LDS.
 //
 // Why: with the GEMMs of that build on the bf16 matrix pipe, the fp32-MFMA attention kernel (attention_f32.hip, 1/16 of the bf16
 // matrix rate, 110 us per ViT-B layer at bs=64) had become 16 % of the step.  Same flash structure as attention_bf16.hip - 64-key
@@ -28,8 +29,14 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KROWB = 128;            // bytes per K row in LDS (64 bf16)
-constexpr int KC = 64, HALF = KC * KROWB, PLANES = 2, STAGE = 2 * PLANES * HALF;   // per stage: K0 | K1 | V0 | V1
-constexpr int NW = 4, PIECES = KC / 8, PPW = PIECES / NW;
+constexpr int KC = 64, HALF = KC * KROWB;   // keys per chunk; one plane image of K or V
+constexpr int PIECES = KC / 8;
+
+// The plane products of one fp32 product, smallest first (ldit.h): two planes -> x1 y0 + x0 y1 + x0 y0; three planes ->
+// x2 y0 + x1 y1 + x0 y2 + x1 y0 + x0 y1 + x0 y0.
+constexpr int n_products(int planes) { return planes == 2 ? 3 : 6; }
+constexpr int prod_x(int planes, int g) { return planes == 2 ? (g == 0 ? 1 : 0) : (g == 0 ? 2 : g == 1 ? 1 : g == 3 ? 1 : 0); }
+constexpr int prod_y(int planes, int g) { return planes == 2 ? (g == 1 ? 1 : 0) : (g == 1 ? 1 : g == 2 ? 2 : g == 4 ? 1 : 0); }
 
 __device__ __forceinline__ void glds16p(const void *gsrc, char *lds_wave_base)
 {
@@ -47,10 +54,17 @@ __device__ __forceinline__ void glds16p_sbase(const void *ubase, unsigned voff_b
                  : "memory");
 }
 
-__global__ void __launch_bounds__(NW * 64, 2) attention_planes2(const bf16_t *__restrict__ Q, const bf16_t *__restrict__ K,
+// PLANES = 2: 64 KB of LDS (two stages of K0 | K1 | V0 | V1); PLANES = 3 (the attention of LDIT_F32X6): 96 KB.  Either way ONE
+// workgroup of eight waves (256 queries) per CU: two waves per SIMD (169 / 217 registers), and one staging of a chunk serves all seven
+// query tiles of a 197-token image.  (Four-wave workgroups, two per CU: 3 % slower with two planes; with three planes the LDS
+// allows only one of them per CU and the kernel ran no faster than the fp32-MFMA attention: 1.42 vs 1.06 ms per ViT-B forward.)
+template <int PLANES, int NW>
+__global__ void __launch_bounds__(NW * 64, 2) attention_planes(const bf16_t *__restrict__ Q, const bf16_t *__restrict__ K,
                                                                 const bf16_t *__restrict__ V, bf16_t *__restrict__ O, int N, int H,
                                                                 int ld_in, int plane_in, int ldo, int nqg)
 {
+    constexpr int STAGE = 2 * PLANES * HALF, NPROD = n_products(PLANES), PPW = PIECES / NW;
+    static_assert(PIECES % NW == 0 && (8 * NW) % 16 == 0, "DMA pieces split evenly over the waves, one swizzle phase per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -151,11 +165,12 @@ __global__ void __launch_bounds__(NW * 64, 2) attention_planes2(const bf16_t *__
             }
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                const bf16x8 k0 = *reinterpret_cast<const bf16x8 *>(kr + (((2 * st + h) ^ sw) * 16));
-                const bf16x8 k1 = *reinterpret_cast<const bf16x8 *>(kr + HALF + (((2 * st + h) ^ sw) * 16));
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[0][st], s[kt], 0, 0, 0);
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[1][st], s[kt], 0, 0, 0);
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0][st], s[kt], 0, 0, 0);
+                bf16x8 kf[PLANES];
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl) kf[pl] = *reinterpret_cast<const bf16x8 *>(kr + pl * HALF + (((2 * st + h) ^ sw) * 16));
+#pragma unroll
+                for (int g = 0; g < NPROD; ++g)
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[prod_x(PLANES, g)], qf[prod_y(PLANES, g)][st], s[kt], 0, 0, 0);
             }
         }
         if (nkeys < NKT * 32) {
@@ -217,23 +232,26 @@ __global__ void __launch_bounds__(NW * 64, 2) attention_planes2(const bf16_t *__
                             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"
                                          : "=v"(vr[pl][dt][u])
                                          : "v"(vaddr), "n"(pl * HALF + (16 * kt + 8 * st + 4 * u + dt) * 256));
-                bf16x8 p0, p1;
+                bf16x8 pp[PLANES];
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
-                    const float pv = s[kt][8 * st + jj];
-                    p0[jj] = (bf16_t)pv;
-                    p1[jj] = (bf16_t)(pv - (float)p0[jj]);
+                    float pv = s[kt][8 * st + jj];
+#pragma unroll
+                    for (int pl = 0; pl < PLANES; ++pl) {
+                        pp[pl][jj] = (bf16_t)pv;
+                        pv -= (float)pp[pl][jj];
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    union { s16x4 v[2]; bf16x8 f; } v0, v1;
-                    v0.v[0] = vr[0][dt][0]; v0.v[1] = vr[0][dt][1];
-                    v1.v[0] = vr[1][dt][0]; v1.v[1] = vr[1][dt][1];
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1.f, p0, o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0.f, p1, o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0.f, p0, o[dt], 0, 0, 0);
+                    union { s16x4 v[2]; bf16x8 f; } vf[PLANES];
+#pragma unroll
+                    for (int pl = 0; pl < PLANES; ++pl) { vf[pl].v[0] = vr[pl][dt][0]; vf[pl].v[1] = vr[pl][dt][1]; }
+#pragma unroll
+                    for (int g = 0; g < NPROD; ++g)
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[prod_x(PLANES, g)].f, pp[prod_y(PLANES, g)], o[dt], 0, 0, 0);
                 }
             }
         }
@@ -270,25 +288,38 @@ __global__ void __launch_bounds__(NW * 64, 2) attention_planes2(const bf16_t *__
 
 // Q, K, V: plane 0 of the operand's column slice; plane s lies `plane_in` elements further in the same row (row stride ld_in).
 // The queries must be pre-multiplied by scale * log2(e).  O: bf16 [B*N, ldo], plane s at column s * H * 64.
-int launch_attention_planes2(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ld_in, int plane_in,
-                             int ldo, hipStream_t stream)
+template <int PLANES>
+static int launch_planes_t(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ld_in, int plane_in,
+                           int ldo, hipStream_t stream)
 {
     if (B <= 0 || N <= 0 || H <= 0) return fail(LDIT_EINVAL, "attention_planes: empty problem");
     if (D != 64) return fail(LDIT_EUNSUPPORTED, "attention_planes: head_dim=%d, only 64 is implemented", D);
     if (!Q || !K || !V || !O) return fail(LDIT_EINVAL, "attention_planes: null operand");
-    if ((ld_in | plane_in) & 7 || (ldo & 3) || ldo < 2 * H * 64 || ld_in < plane_in + H * 64)
-        return fail(LDIT_EINVAL, "attention_planes: bad strides (multiples of 8 in / 4 out, rows wide enough for two planes)");
+    if ((ld_in | plane_in) & 7 || (ldo & 3) || ldo < PLANES * H * 64 || ld_in < (PLANES - 1) * plane_in + H * 64)
+        return fail(LDIT_EINVAL, "attention_planes: bad strides (multiples of 8 in / 4 out, rows wide enough for the planes)");
     if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || (reinterpret_cast<uintptr_t>(O) & 7u))
         return fail(LDIT_EINVAL, "attention_planes: operands must be 16-byte aligned");
     static std::atomic<unsigned long long> attr{0};
-    constexpr int lds = 2 * STAGE;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(attention_planes2), lds, attr)) return rc;
+    constexpr int lds = 2 * 2 * PLANES * HALF, NW = 8;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(attention_planes<PLANES, NW>), lds, attr)) return rc;
     const int nqt = (N + 31) / 32, nqg = (nqt + NW - 1) / NW;
-    hipLaunchKernelGGL(attention_planes2, dim3((unsigned)(B * H * nqg)), dim3(NW * 64), lds, stream, static_cast<const bf16_t *>(Q),
+    hipLaunchKernelGGL((attention_planes<PLANES, NW>), dim3((unsigned)(B * H * nqg)), dim3(NW * 64), lds, stream, static_cast<const bf16_t *>(Q),
                        static_cast<const bf16_t *>(K), static_cast<const bf16_t *>(V), static_cast<bf16_t *>(O), N, H, ld_in, plane_in, ldo,
                        nqg);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
+}
+
+int launch_attention_planes2(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ld_in, int plane_in,
+                             int ldo, hipStream_t stream)
+{
+    return launch_planes_t<2>(Q, K, V, O, B, N, H, D, ld_in, plane_in, ldo, stream);
+}
+
+int launch_attention_planes3(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ld_in, int plane_in,
+                             int ldo, hipStream_t stream)
+{
+    return launch_planes_t<3>(Q, K, V, O, B, N, H, D, ld_in, plane_in, ldo, stream);
 }
 
 }  // namespace ldit

@@ -104,7 +104,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     auto tile_off = [&](int t, unsigned &ka, unsigned &kw) {
         t = t < nkt ? t : nkt - 1;
         int seg = 0;
-        if (p.x.nseg > 1) { seg = t / nk; t -= seg * nk; }
+        if (p.x.nseg > 1) {
+            if (p.x.seg_inner) { const int kb = t / p.x.nseg; seg = t - kb * p.x.nseg; t = kb; }
+            else { seg = t / nk; t -= seg * nk; }
+        }
         ka = (unsigned)(((p.x.seg_a >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)t * BKB);
         kw = (unsigned)(((p.x.seg_w >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)t * BKB);
     };
@@ -498,6 +501,7 @@ static int launch_gemm_bf16_one(const void *A, int lda, const void *W, const flo
     a.A = static_cast<const bf16_t *>(A); a.W = static_cast<const bf16_t *>(W); a.Y = Y; a.Y2 = Y2; a.bias = bias; a.lam = lam;
     a.R = R; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldy = ldy; a.x = x;
     a.ldw = K;
+    if (x.nseg != 0 && diag().seg_order >= 0) a.x.seg_inner = diag().seg_order;
     if (x.nseg != 0) {
         // split-fp32 operands: the planes of a row lie side by side; the widest plane index fixes the W row stride
         if (x.nseg < 1 || x.nseg > 8 || x.splits != 1) return fail(LDIT_EINVAL, "gemm_bf16: bad plane-segment list");

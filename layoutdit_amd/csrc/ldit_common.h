@@ -53,6 +53,8 @@ struct DiagSwitches {
     bool fp8_k16 = false, fp8_noskinny = false;   // LDIT_GEMM_FP8_K16, LDIT_GEMM_FP8_NOSKINNY
     bool direct_epi = false;     // LDIT_GEMM_DIRECT_EPILOGUE=1
     bool attn_bf16_kt4 = false;  // LDIT_ATTN_BF16_KT=4
+    int attn_bf16_nw = -1;       // LDIT_ATTN_BF16_NW=8: eight query tiles per workgroup (one staging of a chunk per 256 queries)
+    int seg_order = -1;          // LDIT_GEMM_SEG_ORDER 0 = plane segments outermost (whole K per segment), 1 = innermost (per k-tile)
 };
 const DiagSwitches &diag();
 void reload_diag();
@@ -153,6 +155,7 @@ struct GemmExtra {
     // K in the launch arguments stays the per-plane depth.  nseg = 0: ordinary bf16 GEMM.
     int nseg = 0;
     unsigned seg_a = 0, seg_w = 0;
+    int seg_inner = 0;                 // 1: the segments are walked per 64-deep k-tile (k-tile outermost) instead of per whole K
     int nsplit_out = 0;                // EPI_GELU_SPLIT: planes of the output row (row stride ldy = nsplit_out * N)
 };
 
@@ -226,12 +229,12 @@ int launch_gemm_bf16_tr(const void *A, int lda, bool a_reduction_major, const vo
                         int M, int N, int K, int epi, const GemmExtra &x, hipStream_t stream);
 int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream, float mul = 1.0f);
 // split-fp32 build: dst bf16 [rows, planes * cols] = the `planes` bf16 planes of src fp32 [rows, cols] (row stride lds) side by side
-int launch_attention_planes(const float *Q, const float *K, const float *V, void *O, int B, int N, int H, int D, int ldq,
-                            int ldk, int ldv, int ldo, float scale, int planes, hipStream_t stream);
 int launch_split_planes(const float *src, int lds, void *dst, int rows, int cols, int planes, hipStream_t stream, float mul = 1.0f);
 // f32x3 build: attention on bf16-plane operands (attention_planes.hip); queries pre-multiplied by scale * log2(e)
 int launch_attention_planes2(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ld_in, int plane_in,
                              int ldo, hipStream_t stream);
+int launch_attention_planes3(const void *Q, const void *K, const void *V, void *O, int B, int N, int H, int D, int ld_in, int plane_in,
+                             int ldo, hipStream_t stream);     // three planes, six products (f32x6)
 int launch_layernorm_splitout(const float *X, const float *g, const float *b, void *Y, int64_t rows, int C, float eps, int planes,
                               hipStream_t stream);
 // fp8: the per-tensor part of the accumulator's dequantisation is d_act[0] when d_act is non-null (device), else the host

@@ -73,9 +73,9 @@ class DiTEncoder(nn.Module):
         attention on bf16; needs one ``calibrate_fp8(sample_batch)`` call before the first forward).
         ``"f32x3"`` / ``"f32x6"``: the fp32 forward with every GEMM operand held as two / three bf16 planes and every product
         formed from three / six plane products on the bf16 MFMA (16x the fp32 matrix rate) with fp32 accumulation; LayerNorm,
-        attention, erf-GELU and the residual stream exactly as ``"f32"``.  ``"f32x6"`` has the error of fp32 arithmetic (5e-7 vs
-        float64), ``"f32x3"`` 3-5e-6 - inside the fp32 build's own parity gates, 200x inside the reference's 1e-3 - at more than
-        twice the speed of ``"f32"`` (include/ldit.h, LDIT_F32X3).
+        softmax, erf-GELU and the residual stream exactly as ``"f32"``.  ``"f32x6"`` has the error of fp32 arithmetic (6-8e-7 vs
+        float64, under the ``"f32"`` build's own) at 1.3x its speed, ``"f32x3"`` 4.4-5.6e-6 - inside the fp32 build's own parity
+        gates, 180x inside the reference's 1e-3 - at 2.3x (include/ldit.h, LDIT_F32X3).
 
         TRAINING (``.train()`` + ``loss.backward()``, ref trainer.py:168-180) is mixed precision for the ``"f32"`` and
         ``"bf16"`` builds alike: bf16 MFMA operands, fp32 accumulation, fp32 residual stream / LayerNorm / softmax /

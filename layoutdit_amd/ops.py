@@ -249,18 +249,18 @@ def split_planes(x: torch.Tensor, planes: int) -> torch.Tensor:
     return out
 
 
-def attention_planes2(qkv_planes: torch.Tensor, heads: int) -> torch.Tensor:
-    """The attention of the f32x3 build: ``qkv_planes`` bf16 [B, N, 2 * 3C] = the two planes of the fused q|k|v rows (q pre-multiplied
-    by scale * log2 e); returns the two planes of the fp32 result, bf16 [B, N, 2 * C]."""
+def attention_planes(qkv_planes: torch.Tensor, heads: int, planes: int) -> torch.Tensor:
+    """The attention of the split-fp32 builds: ``qkv_planes`` bf16 [B, N, planes * 3C] = the planes of the fused q|k|v rows (q
+    pre-multiplied by scale * log2 e); returns the planes of the fp32 result, bf16 [B, N, planes * C]."""
     lib = _lib.load()
     if not qkv_planes.is_cuda or qkv_planes.dtype != torch.bfloat16 or not qkv_planes.is_contiguous():
         raise ValueError("qkv_planes: expected a contiguous bfloat16 GPU tensor")
     B, N, W6 = qkv_planes.shape
-    Cc = W6 // 6
-    out = torch.empty((B, N, 2 * Cc), device=qkv_planes.device, dtype=torch.bfloat16)
+    Cc = W6 // (3 * planes)
+    out = torch.empty((B, N, planes * Cc), device=qkv_planes.device, dtype=torch.bfloat16)
     base = qkv_planes.data_ptr()
-    _launch(_device(qkv_planes), lib.ldit_attention_planes2, base, base + 2 * Cc, base + 4 * Cc, _ptr(out), B, N, heads, Cc // heads,
-            W6, 3 * Cc, 2 * Cc)
+    _launch(_device(qkv_planes), lib.ldit_attention_planes, base, base + 2 * Cc, base + 4 * Cc, _ptr(out), B, N, heads, Cc // heads,
+            W6, 3 * Cc, planes * Cc, planes)
     return out
 
 

@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from layoutdit_amd import _lib, ops  # noqa: E402
 PL = int(os.environ.get("PLANES", "2"))
 TILES = ("2", "3", "4", "5", "auto")
+ORDER = os.environ.get("ORDER_AB") == "1"        # A/B of the segment order (outermost / innermost) on the picker's tiling instead
+if ORDER:
+    TILES = ("outer", "inner")
 M, C = int(os.environ.get("M", 64 * 197)), 768
 F = 4 * C
 for name, n, k, epi in (("qkv", 3 * C, C, _lib.EPI_BIAS), ("o_proj", C, C, _lib.EPI_SCALE_RESID), ("fc1", F, C, _lib.EPI_BIAS_GELU),
@@ -22,7 +25,10 @@ for name, n, k, epi in (("qkv", 3 * C, C, _lib.EPI_BIAS), ("o_proj", C, C, _lib.
     res = {t: [] for t in TILES}
     for rnd in range(5):
         for t in res:
-            _lib.set_switch("LDIT_GEMM_BF16_TILE", None if t == "auto" else t)
+            if ORDER:
+                _lib.set_switch("LDIT_GEMM_SEG_ORDER", "0" if t == "outer" else "1")
+            else:
+                _lib.set_switch("LDIT_GEMM_BF16_TILE", None if t == "auto" else t)
             for _ in range(3): ops.linear_planes(xp, wp, PL, b, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -30,6 +36,7 @@ for name, n, k, epi in (("qkv", 3 * C, C, _lib.EPI_BIAS), ("o_proj", C, C, _lib.
             e1.record(); torch.cuda.synchronize()
             res[t].append(e0.elapsed_time(e1) / 20 * 1e3)
     _lib.set_switch("LDIT_GEMM_BF16_TILE", None)
+    _lib.set_switch("LDIT_GEMM_SEG_ORDER", None)
     med = {t: statistics.median(v) for t, v in res.items()}
     fl = 2.0 * M * n * k * (3 if PL == 2 else 6)
     print(f"planes={PL} M={M:6d} {name:7s} N={n:5d} K={k:5d}  " + "  ".join(f"{t}:{med[t]:7.1f}us" for t in res) +

@@ -94,26 +94,28 @@ def test_linear_planes_vs_float64(planes, M, N, K):
     _lib.set_switch("LDIT_GEMM_BF16_TILE", None)
 
 
+@pytest.mark.parametrize("planes", [2, 3])
 @pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 1025, 2), (3, 64, 1), (2, 33, 2), (1, 130, 4)])
-def test_attention_planes_vs_float64(B, N, H):
+def test_attention_planes_vs_float64(B, N, H, planes):
     """attention_planes.hip against float64 softmax(q k^T / sqrt(D)) v on the unsplit operands: whole chunks, a ragged last chunk
-    (N = 197: 5 keys; N = 1025: 1 key), a single partial chunk, a query tile past the end.  The error budget is the planes' 2^-17
-    on q, k (amplified by the exp), p and v: <= 2e-5 relative-L2, the fp32 gate.  A large-logit head forces the deferred rescale."""
+    (N = 197: 5 keys; N = 1025: 1 key), a single partial chunk, a query tile past the end.  The error budget of two planes is their
+    2^-17 on q, k (amplified by the exp), p and v: <= 2e-5 relative-L2, the fp32 gate; three planes (six products): fp32 level,
+    <= 2e-6.  A large-logit head forces the deferred rescale."""
     D, Cc = 64, 64 * H
     rs = np.random.RandomState(7 + N)
     q, k, v = (rs.standard_normal((B, N, Cc)).astype(np.float32) for _ in range(3))
     q[0, :, :D] *= 6.0                                            # scores of +-50 and a maximum that keeps moving: rescale path
     scale = D ** -0.5
     qkv = np.concatenate([q * np.float32(scale * 1.4426950408889634), k, v], axis=2)
-    planes = ops.split_planes(_dev(qkv.reshape(B * N, 3 * Cc)), 2).reshape(B, N, 6 * Cc)
-    out = ops.attention_planes2(planes, H)
-    got = (out[..., :Cc].double() + out[..., Cc:].double()).cpu().numpy()
+    qp = ops.split_planes(_dev(qkv.reshape(B * N, 3 * Cc)), planes).reshape(B, N, planes * 3 * Cc)
+    out = ops.attention_planes(qp, H, planes)
+    got = sum(out[..., s * Cc:(s + 1) * Cc].double() for s in range(planes)).cpu().numpy()
     qh, kh, vh = (t.astype(np.float64).reshape(B, N, H, D).transpose(0, 2, 1, 3) for t in (q, k, v))
     sc = qh @ kh.transpose(0, 1, 3, 2) * scale
     p = np.exp(sc - sc.max(-1, keepdims=True))
     ref = ((p / p.sum(-1, keepdims=True)) @ vh).transpose(0, 2, 1, 3).reshape(B, N, Cc)
-    assert rel_l2(got, ref) < 2e-5, rel_l2(got, ref)
-    assert torch.equal(out, ops.attention_planes2(planes, H))
+    assert rel_l2(got, ref) < (2e-5 if planes == 2 else 2e-6), rel_l2(got, ref)
+    assert torch.equal(out, ops.attention_planes(qp, H, planes))
 
 
 def _model(cfg, wseed, dtype):
