@@ -401,9 +401,16 @@ static int launch_attn(const void *Q, const void *K, const void *V, void *O, int
     // scale == 0: Q is pre-multiplied by scale * log2(e) (PRE, the packed inference path); otherwise the factor is applied here.
     static std::atomic<unsigned long long> set2{0}, set4{0}, set2p{0};      // per-device bookkeeping (ensure_dynamic_lds)
     // (eight query tiles per workgroup - half the DMA pieces and K/V traffic per tile - measured equal: 108.6 vs 107.8 us at N = 1025)
-    static std::atomic<unsigned long long> set2p8{0};
-    if (scale == 0.0f && diag().attn_bf16_nw == 8) LDIT_TRY_RC(go_nw(attention_bf16<2, 8, OUT_FP8, true>, 8, 2 * 2 * 2 * 32 * KROWB, set2p8));
+    // Round 3: five to eight query tiles (N = 129 .. 256: the 197 tokens of a 224 x 224 image) run as ONE eight-wave workgroup per
+    // (image, head) - one staging of every chunk instead of two, no half-empty second workgroup: 27.3 -> 23.5 us at bs=64, 16.2 -> 14.7 us
+    // at bs=32 (scripts/attn_bf16_bench.py, interleaved); long sequences stay on four-wave workgroups (N = 1025: 102.6 vs 105 us).  A
+    // query tile's arithmetic does not depend on its workgroup: bit-identical either way (LDIT_ATTN_BF16_NW = 4 / 8 forces one).
+    static std::atomic<unsigned long long> set2p8{0}, set28{0};
+    const int force_nw = diag().attn_bf16_nw;
+    const bool wide = force_nw == 8 || (force_nw != 4 && nqt > 4 && nqt <= 8);
+    if (scale == 0.0f && wide) LDIT_TRY_RC(go_nw(attention_bf16<2, 8, OUT_FP8, true>, 8, 2 * 2 * 2 * 32 * KROWB, set2p8));
     else if (scale == 0.0f) LDIT_TRY_RC(go(attention_bf16<2, NW, OUT_FP8, true>, 2 * 2 * 2 * 32 * KROWB, set2p));
+    else if (wide && !kt4) LDIT_TRY_RC(go_nw(attention_bf16<2, 8, OUT_FP8, false>, 8, 2 * 2 * 2 * 32 * KROWB, set28));
     else if (kt4) LDIT_TRY_RC(go(attention_bf16<4, NW, OUT_FP8, false>, 2 * 2 * 4 * 32 * KROWB, set4));
     else LDIT_TRY_RC(go(attention_bf16<2, NW, OUT_FP8, false>, 2 * 2 * 2 * 32 * KROWB, set2));
     LDIT_HIP_CHECK(hipGetLastError());

@@ -86,6 +86,22 @@ def test_attention_bf16(B, N, H):
     assert np.isfinite(o).all()
 
 
+@pytest.mark.parametrize("N", [197, 130, 256, 257, 100])
+def test_attention_bf16_workgroup_width_does_not_change_a_bit(N):
+    """Five to eight query tiles (N = 129 .. 256) run as one eight-wave workgroup per (image, head), everything else on four-wave
+    workgroups (attention_bf16.hip, launch_attn).  A query tile's arithmetic does not depend on its workgroup: both widths forced,
+    both entry modes, bit-equal - so batch and shape invariance of the bf16 / fp8 builds and of the train step are untouched."""
+    B, H, D = 2, 3, 64
+    q, k, v = (torch.from_numpy(_bf16_round(_rand(220 + i, B, N, H * D))).to(DEV).to(torch.bfloat16) for i in range(3))
+    got = {}
+    for nw in ("4", "8", None):
+        _lib.set_switch("LDIT_ATTN_BF16_NW", nw)
+        got[nw] = (ops.attention_bf16(q, k, v, heads=H), ops.attention_bf16(q, k, v, heads=H, prescaled=True))
+    _lib.set_switch("LDIT_ATTN_BF16_NW", None)
+    for mode in (0, 1):
+        assert torch.equal(got["4"][mode], got["8"][mode]) and torch.equal(got["4"][mode], got[None][mode])
+
+
 @pytest.mark.parametrize("B,N,H", [(1, 197, 3), (2, 33, 2), (1, 64, 1), (1, 257, 2), (1, 1025, 3), (2, 128, 2)])
 def test_attention_bf16_prescaled_queries(B, N, H):
     """The packed inference path hands the kernel q' = (scale log2 e) q (folded into W_q at pack time) and scale = 0: scores are
