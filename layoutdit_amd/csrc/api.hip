@@ -51,6 +51,7 @@ DiagSwitches read_switches()
     d.direct_epi = is("LDIT_GEMM_DIRECT_EPILOGUE", '1');
     d.attn_bf16_kt4 = is("LDIT_ATTN_BF16_KT", '4');
     d.seg_order = digit("LDIT_GEMM_SEG_ORDER", 0, 1);
+    if (const char *e = getenv("LDIT_PLANES_TAIL_WAVES")) d.planes_tail_waves = atol(e);
     d.attn_bf16_nw = digit("LDIT_ATTN_BF16_NW", 4, 8);
     return d;
 }

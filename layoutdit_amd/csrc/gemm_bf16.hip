@@ -310,36 +310,53 @@ int launch_h(const GemmArgsH &a, hipStream_t stream)
 template <int EPI>
 __global__ void __launch_bounds__(64) gemm_bf16_tail(const GemmArgsH p)
 {
-    constexpr int D = 8;                                  // steps per register set (two sets: 32 steps = 64 KB in flight per wave)
+    // A register set holds two GROUPS of four 16-deep steps; a group = one 64-deep k-tile of one plane segment (ordinary GEMM: one
+    // segment, so groups are the k-tiles in order - what this kernel always did).  Split-fp32 operands (GemmExtra::nseg): the groups
+    // are walked in the tile kernels' order (k-tile outermost when seg_inner, else segment outermost), so that a row gets the tile
+    // kernels' bits here too - which lets small batches of those builds run on this latency-oriented kernel.
+    constexpr int GPS = 2;                                // groups per register set (two sets: 16 steps = 32 KB in flight per wave)
     const int lane = threadIdx.x, c32 = lane & 31, h = lane >> 5;
     const int nct = (p.N + 31) / 32;
     const int n0 = (blockIdx.x % nct) * 32, m0 = (blockIdx.x / nct) * 32;
     const int ra = m0 + c32 < p.M ? m0 + c32 : p.M - 1, rw = n0 + c32 < p.N ? n0 + c32 : p.N - 1;
-    const bf16_t *ap = p.A + (size_t)ra * p.lda + 8 * h, *wp = p.W + (size_t)rw * p.K + 8 * h;
-    const int nsteps = p.K / 16;
+    const bf16_t *ap = p.A + (size_t)ra * p.lda + 8 * h, *wp = p.W + (size_t)rw * p.ldw + 8 * h;
+    const int nkb = p.K / BKB, nseg = p.x.nseg > 0 ? p.x.nseg : 1, ngroups = nkb * nseg;
     f32x16 acc[1][1];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.0f;
-    bf16x8 xa0[D], wb0[D], xa1[D], wb1[D];
-    auto ld = [&](bf16x8(&xa)[D], bf16x8(&wb)[D], int s0) {
+    bf16x8 xa0[4 * GPS], wb0[4 * GPS], xa1[4 * GPS], wb1[4 * GPS];
+    auto ld = [&](bf16x8(&xa)[4 * GPS], bf16x8(&wb)[4 * GPS], int g0) {
 #pragma unroll
-        for (int u = 0; u < D; ++u) {
-            const int s = s0 + u < nsteps ? s0 + u : nsteps - 1;          // clamped: a step past the end is loaded, never multiplied
-            xa[u] = *reinterpret_cast<const bf16x8 *>(ap + 16 * s);
-            wb[u] = *reinterpret_cast<const bf16x8 *>(wp + 16 * s);
+        for (int gi = 0; gi < GPS; ++gi) {
+            int G = g0 + gi < ngroups ? g0 + gi : ngroups - 1;            // clamped: a group past the end is loaded, never multiplied
+            int seg = 0, kb = G;
+            if (p.x.nseg > 1) {
+                if (p.x.seg_inner) { kb = G / nseg; seg = G - kb * nseg; }
+                else { seg = G / nkb; kb = G - seg * nkb; }
+            }
+            const unsigned ka = ((p.x.seg_a >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)kb * BKB;
+            const unsigned kw = ((p.x.seg_w >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)kb * BKB;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                xa[4 * gi + st] = *reinterpret_cast<const bf16x8 *>(ap + ka + 16 * st);
+                wb[4 * gi + st] = *reinterpret_cast<const bf16x8 *>(wp + kw + 16 * st);
+            }
         }
     };
-    auto mm = [&](const bf16x8(&xa)[D], const bf16x8(&wb)[D], int s0) {
+    auto mm = [&](const bf16x8(&xa)[4 * GPS], const bf16x8(&wb)[4 * GPS], int g0) {
 #pragma unroll
-        for (int u = 0; u < D; ++u)
-            if (s0 + u < nsteps) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[u], xa[u], acc[0][0], 0, 0, 0);
+        for (int gi = 0; gi < GPS; ++gi)
+            if (g0 + gi < ngroups)
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[4 * gi + st], xa[4 * gi + st], acc[0][0], 0, 0, 0);
     };
     ld(xa0, wb0, 0);
-    for (int s0 = 0; s0 < nsteps; s0 += 2 * D) {
-        ld(xa1, wb1, s0 + D);
-        mm(xa0, wb0, s0);
-        ld(xa0, wb0, s0 + 2 * D);
-        mm(xa1, wb1, s0 + D);
+    for (int g0 = 0; g0 < ngroups; g0 += 2 * GPS) {
+        ld(xa1, wb1, g0 + GPS);
+        mm(xa0, wb0, g0);
+        ld(xa0, wb0, g0 + 2 * GPS);
+        mm(xa1, wb1, g0 + GPS);
     }
     if ((n0 + 32 <= p.N) && ((p.ldy & 3) == 0)) store_h<1, 1, EPI, 1>(p, acc, m0, n0, lane);
     else store_h<1, 1, EPI, 2>(p, acc, m0, n0, lane);
@@ -357,8 +374,14 @@ int launch_tail(const GemmArgsH &a, hipStream_t stream)
 template <int EPI>
 int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
 {
-    // (split-fp32 operands walk their plane segments in the tile kernels only)
-    if (a.M <= 64 && a.x.splits == 1 && a.x.nseg == 0 && !diag().bf16_tile_env) return launch_tail<EPI>(a, stream);
+    if (a.M <= 64 && a.x.splits == 1 && !diag().bf16_tile_env) return launch_tail<EPI>(a, stream);
+    // Split-fp32 operands at serving sizes: the plane products make the k-loop 3 - 6 x as deep (K' = 2 304 ... 18 432) while a few
+    // images give the tile kernels only a handful of tiles - twelve 128 x 128 tiles walking K' = 9 216 took 170 us.  The one-wave-per-
+    // 32 x 32-tile kernel spreads the same work over hundreds of waves (bit-identical rows).  It re-reads its operands from L2 per
+    // wave, so it only pays while there are few of them: up to 700 waves (scripts/latency_bench.py, f32x3 at bs = 1 / 2 / 4: 3.03 /
+    // 3.04 / 3.07 ms on the tile kernels alone, 1.49 / 2.24 / 2.77 ms with this rule; 6 144 waves: 1.49 / 2.42 / 3.83 ms).
+    if (a.x.nseg > 1 && a.x.splits == 1 && !diag().bf16_tile_env && (long)((a.M + 31) / 32) * ((a.N + 31) / 32) <= diag().planes_tail_waves)
+        return launch_tail<EPI>(a, stream);
     // Time model fitted to scripts/gemm_bf16_bench.py on ViT-B / ViT-L shapes, M = 3 k .. 25 k (profiles/README.md), in us:
     //   256 x 256, 8 waves (one workgroup per CU):  strict rounds of 256 tiles, each  a[epi] + 19.5e-3 K
     //   128 x 128 (two per CU, they overlap each other's prologue / epilogue):  rounds of 256 tiles, each  r[epi] + 7.6e-3 K,
