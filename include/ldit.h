@@ -51,7 +51,9 @@ enum ldit_dtype {
                       16 significant bits) and every product computed as p1.q0 + p0.q1 + p0.q0 on the bf16 MFMA (16x the fp32
                       matrix rate) with fp32 accumulation - "bf16x3" -, the two products of the attention included.  Residual stream, LayerNorm,
                       softmax, erf-GELU, biases and taps are fp32 exactly as in LDIT_F32.  Whole-path error vs float64: 4.4 - 5.6e-6
-                      relative L2 (LDIT_F32: 7 - 9e-7), i.e. inside the fp32 build's own parity gates (2e-5), 180x inside the north-star 1e-3. */
+                      relative L2 (LDIT_F32: 7 - 9e-7), i.e. inside the fp32 build's own parity gates (2e-5), 180x inside the north-star 1e-3.
+                      The error of a dot product is 2^-17 of its TERMS: with activation outliers (LayerNorm channels x 60) the worst
+                      element reaches 1.2e-3 of max(|ref|, 1) while the relative L2 stays 1.6e-5 - check parity per checkpoint. */
     LDIT_F32X6 = 5  /* the same with THREE planes (24 significant bits) and the six plane products down to 2^-24: fp32-grade error
                       (6 - 8e-7 vs float64: under the fp32 MFMA path's on every tap, at that of ATen's CPU fp32 forward) at 6 bf16 MFMAs per product */
 };

@@ -229,3 +229,39 @@ def test_backbone_feature_maps_and_training_entry(golden_dir, dtype):
     grads = [p.grad for p in bb.dit.parameters() if p.grad is not None]
     assert len(grads) > 100 and all(bool(torch.isfinite(g).all()) for g in grads)
     assert float(bb.dit.encoder.layer[0].intermediate.dense.weight.grad.abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("dtype", ["f32x3", "f32x6"])
+def test_outlier_channel_stress(dtype):
+    """Pretrained BEiT / DiT checkpoints carry LayerNorm channels tens of times larger than the rest; synthetic N(0, 0.02)
+    weights do not.  The stress of tests/test_gpu_lowp_pinning.py (three LayerNorm gammas and two fc1 rows x 60 in every layer, ViT-Tiny
+    bs=2) on the split builds.  A bf16 plane has fp32's exponent range and a plane product is exact, so nothing saturates or
+    underflows - but the error of a dot product is RELATIVE TO ITS TERMS (2^-17 sum |a_k w_k| for two planes, 2^-24 for fp32 and for
+    three planes), and with x60 channels the terms dwarf most results.  Measured (gpurun_out/split_fp32_outlier_stress_*.json, worst tap):
+      f32 (fp32 MFMA)  rel-L2 1.3e-6   worst element 6.2e-5 of max(|ref|, 1)
+      f32x6            rel-L2 1.0e-6   worst element 4.3e-5      -> held to the fp32 gates here too
+      f32x3            rel-L2 1.6e-5   worst element 1.2e-3      -> relative-L2 still inside the fp32 gate, the worst ELEMENT at the
+                                                                    north-star's 1e-3: sixteen operand bits are what they are.
+    f32x3 is therefore gated at 2e-5 / 2e-3 on this stress and documented as the throughput option for checkpoints whose parity has
+    been checked; f32x6 is the build that is fp32 everywhere."""
+    from tests.test_gpu_lowp_pinning import _outlier_weights
+    cfg = cfgs.vit_tiny()
+    w = _outlier_weights(cfg, 4, 60.0)
+    x = synth.synth_images(2, 224, 224, seed=1234)
+    m = DiTEncoder(cfg, compute_dtype=dtype).load_numpy(w).to(DEV).eval()
+    m32 = DiTEncoder(cfg).load_numpy(w).to(DEV).eval()
+    out, out32 = _run(m, x), _run(m32, x)
+    ref, _ = oracle.vit_forward(cfg, w, x)
+    rec = {}
+    for t, r in zip(cfg.taps, ref):
+        h = out.hidden_states[t].cpu().numpy()
+        rec[str(t)] = {"rel_l2": float(rel_l2(h, r)), "max_rel": float(max_rel(h, r)),
+                       "rel_l2_of_the_f32_build": float(rel_l2(out32.hidden_states[t].cpu().numpy(), r)),
+                       "max_rel_of_the_f32_build": float(max_rel(out32.hidden_states[t].cpu().numpy(), r))}
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, f"split_fp32_outlier_stress_{dtype}.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    for t, v in rec.items():
+        assert v["rel_l2"] < 2e-5 and v["max_rel"] < (1e-4 if dtype == "f32x6" else 2e-3), (t, v)
+        if dtype == "f32x6":
+            assert v["rel_l2"] < 1.5 * v["rel_l2_of_the_f32_build"] and v["max_rel"] < 2.0 * v["max_rel_of_the_f32_build"], (t, v)
