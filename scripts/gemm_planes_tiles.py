@@ -6,7 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from layoutdit_amd import _lib, ops  # noqa: E402
 PL = int(os.environ.get("PLANES", "2"))
-TILES = ("2", "3", "4", "5", "auto")
+TILES = tuple(os.environ.get("TILES", "2,3,4,5,auto").split(","))
 ORDER = os.environ.get("ORDER_AB") == "1"        # A/B of the segment order (outermost / innermost) on the picker's tiling instead
 if ORDER:
     TILES = ("outer", "inner")
