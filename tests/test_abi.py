@@ -83,6 +83,31 @@ def test_null_and_misaligned_arguments_fail_before_any_launch():
     assert rc == _lib.LDIT_EUNSUPPORTED
 
 
+def test_split_fp32_entries_validate_before_any_launch():
+    """The building blocks of the split-fp32 builds (ldit_split_f32_planes, ldit_layernorm_f32_planes, ldit_linear_planes,
+    ldit_attention_planes, ldit_embed_bf16): plane counts other than 2 / 3, a k-depth that is not a multiple of the bf16 k-tile, rows
+    too short for their planes and null / misaligned operands are refused on the host, with a message, before anything is launched."""
+    lib = _lib.load()
+    err = lambda: lib.ldit_last_error().decode()                                                    # noqa: E731
+    assert lib.ldit_linear_planes(16, 128, 16, None, 16, 64, 8, 64, 64, 0, None, None, None, 4, None) == _lib.LDIT_EINVAL and "planes" in err()
+    assert lib.ldit_linear_planes(16, 64, 16, None, 16, 64, 8, 64, 64, 0, None, None, None, 2, None) == _lib.LDIT_EINVAL      # lda < 2 K
+    assert "leading dimension" in err()
+    assert lib.ldit_linear_planes(16, 96, 16, None, 16, 64, 8, 64, 48, 0, None, None, None, 2, None) == _lib.LDIT_EUNSUPPORTED
+    assert "multiple of 64" in err()
+    assert lib.ldit_linear_planes(16, 128, 16, None, 16, 64, 8, 64, 64, 1, None, None, None, 2, None) == _lib.LDIT_EINVAL    # GELU: ldy != 2 N
+    assert "planes" in err()
+    assert lib.ldit_linear_planes(16, 128, 16, None, 16, 64, 8, 64, 64, 2, None, None, None, 2, None) == _lib.LDIT_EINVAL    # residual epilogue without lam / R
+    assert lib.ldit_split_f32_planes(16, 64, 16, 4, 64, 5, None) == _lib.LDIT_EINVAL and "planes" in err()
+    assert lib.ldit_split_f32_planes(16, 62, 16, 4, 62, 2, None) == _lib.LDIT_EINVAL                                       # cols % 4
+    assert lib.ldit_layernorm_f32_planes(16, 16, 16, 16, 4, 64, 1e-12, 1, None) == _lib.LDIT_EINVAL and "planes" in err()
+    assert lib.ldit_attention_planes(16, 16, 16, 16, 1, 8, 1, 64, 384, 192, 128, 4, None) == _lib.LDIT_EINVAL and "planes" in err()
+    assert lib.ldit_attention_planes(16, 16, 16, 16, 1, 8, 1, 32, 384, 192, 128, 2, None) == _lib.LDIT_EUNSUPPORTED         # head_dim 32
+    assert lib.ldit_attention_planes(16, 16, 16, 16, 1, 8, 1, 64, 384, 192, 64, 2, None) == _lib.LDIT_EINVAL                # output row too short
+    assert lib.ldit_attention_planes(16, 16, 16, None, 1, 8, 1, 64, 384, 192, 128, 2, None) == _lib.LDIT_EINVAL
+    assert lib.ldit_embed_bf16(16, 16, 16, 16, 16, 16, 16, 1, 3, 20, 20, 10, 64, None) == _lib.LDIT_EUNSUPPORTED and "multiple of 64" in err()
+    assert lib.ldit_embed_bf16(16, 16, 16, 16, 16, 16, None, 1, 3, 32, 32, 16, 64, None) == _lib.LDIT_EINVAL
+
+
 def test_gemm_index_space_guards_at_the_boundary():
     """Guard arithmetic of ldit_linear_f32: operands are indexed with 32-bit ELEMENT offsets from the matrix
     origin (limit 2^31 elements) and the panel kernel keeps a 32-bit BYTE offset inside one 304-row tile (limit: row
