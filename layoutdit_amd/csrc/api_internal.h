@@ -87,7 +87,7 @@ inline PackedMap packed_map(const Geo &g, int dtype)
     return m;
 }
 
-struct Workspace { size_t h, y, big, att, total; };   // byte offsets (att: split-fp32 builds only)
+struct Workspace { size_t h, y, big, total; };   // byte offsets
 
 inline Workspace workspace_map(const Geo &g, int batch, int dtype)
 {
@@ -104,7 +104,6 @@ inline Workspace workspace_map(const Geo &g, int batch, int dtype)
         w.y = take(M * g.C * 2 * S);
         const size_t qkv = M * 3 * g.C * 4, hid = M * g.F * 2 * S, patches = (size_t)batch * g.P * g.Kp * 2 * S;
         w.big = take(std::max(std::max(qkv, hid), patches));
-        w.att = 0;
         w.total = o;
         return w;
     }
@@ -112,7 +111,6 @@ inline Workspace workspace_map(const Geo &g, int batch, int dtype)
     size_t big = M * wide * act;   // fused q|k|v, later the MLP hidden (never live together)
     if (dtype != LDIT_F32 && big < (size_t)batch * g.P * g.Kp * 2) big = (size_t)batch * g.P * g.Kp * 2;   // before layer 0: bf16 im2col of the batch
     w.big = take(big);
-    w.att = 0;
     w.total = o;
     return w;
 }
