@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
         kw = (unsigned)(((p.x.seg_w >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)t * BKB);
     };
     auto issue_range = [&](int stage, unsigned ka, unsigned kw, int lo, int hi) {
+#ifdef LDIT_BF16_VADDR_DMA           // A/B build only: per-lane 64-bit source addresses through the builtin, as in rounds 1-2
         char *base = smem + stage * (ROWS * ROWB);
 #pragma unroll
         for (int u = 0; u < NLW; ++u) {
@@ -121,6 +122,18 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
             const bf16_t *opnd = isA ? p.A : p.W;
             glds16h(opnd + (src[u] + (isA ? ka : kw)), base + piece * 1024);
         }
+#else
+        // the k-tile's column offset travels in the scalar base, the lane's row / chunk offset is the kernel constant src[u]
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)(smem + stage * (ROWS * ROWB))));
+        // (made scalar by hand: the tile offsets come out of an integer division, which hipcc evaluates on the vector unit)
+        const bf16_t *abase = uniform_ptr(p.A + ka), *wbase = uniform_ptr(p.W + kw);
+#pragma unroll
+        for (int u = 0; u < NLW; ++u) {
+            if (u < lo || u >= hi) continue;
+            const int piece = (wave % LW) + LW * u;
+            glds16h_sbase(8 * piece < BM ? abase : wbase, 2u * src[u], dst + piece * 1024);
+        }
+#endif
     };
 
     f32x16 acc[TM][TN];

@@ -21,6 +21,29 @@ __device__ __forceinline__ void glds16h(const void *gsrc, char *lds_wave_base)
 }
 
 
+// LDS-DMA piece with a wave-uniform 64-bit base in SGPRs and a per-lane 32-bit BYTE offset: `global_load_lds_dwordx4 voff, s[base]`.
+// The builtin takes a per-lane 64-bit pointer: two or three VALU instructions per piece (offset + k, widen, add) and a live VGPR
+// pair; here the k-tile's advance lives in the scalar base and the lane offset is a constant of the kernel.  M0 (the LDS
+// destination) is compiler-reserved: saved and restored inside the statement (cdna guide 5.7).  Invisible to hipcc's waitcnt pass:
+// every consumer of the staged data sits behind an explicit s_waitcnt vmcnt.
+__device__ __forceinline__ void glds16h_sbase(const void *ubase, unsigned voff_bytes, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_bytes), "s"(ubase), "s"(lds_dst)
+                 : "memory");
+}
+
+// a wave-uniform pointer that hipcc computed on the vector unit (integer divisions, 64-bit multiplies) -> scalar registers
+template <typename T>
+__device__ __forceinline__ const T *uniform_ptr(const T *q)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const T *>(((unsigned long long)hi << 32) | lo);
+}
+
 struct GemmArgsH {
     const bf16_t *A;     // [M, K] bf16
     const bf16_t *W;     // [N, K] bf16

@@ -88,6 +88,23 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
     auto issue = [&](int stage, int k0) {                     // k0: first reduction index of the k-tile
         char *base = smem + stage * STAGE;
         const bool ragged = k0 + BKB > p.K;                   // block-uniform: only the last k-tile of the matrix
+#ifndef LDIT_BF16_VADDR_DMA
+        // (the 320-row tile has no register left for the three scalar bases' set-up: it would spill one VGPR)
+        if (TM < 5 && !ragged) {
+            // every k-tile but a ragged last one: the tile's advance travels in a scalar base, the lane's offset is the kernel
+            // constant src[u] (glds16h_sbase, gemm_bf16_common.h) - no vector address arithmetic per piece
+            const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)base));
+            const bf16_t *a_k = uniform_ptr(p.A + (unsigned)k0), *a_r = uniform_ptr(p.A + (size_t)k0 * (size_t)p.lda),
+                         *w_r = uniform_ptr(p.W + (size_t)k0 * (size_t)p.ldw);
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int piece = wave + NWAVES * u;
+                const bool isA = 8 * piece < BM;
+                glds16h_sbase((!TA && isA) ? a_k : isA ? a_r : w_r, 2u * src[u], dst + piece * 1024);
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int piece = wave + NWAVES * u;

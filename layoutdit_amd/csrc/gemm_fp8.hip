@@ -168,12 +168,19 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_fp8_mfma(con
         }
     }
     auto issue = [&](int stage, int k0) {
-        char *base = smem + stage * (ROWS * ROW8);
+        // the k-tile's advance travels in a scalar base, the lane's row / chunk offset is the kernel constant src[u]: no vector address
+        // arithmetic per piece (`global_load_lds_dwordx4 voff, s[base]`; invisible to hipcc's waitcnt pass - every hand-over below
+        // carries its explicit s_waitcnt vmcnt)
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)(smem + stage * (ROWS * ROW8))));
+        const unsigned char *abase = p.A + k0, *wbase = p.W + k0;
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int piece = wave + NWAVES * u;
-            const unsigned char *opnd = 8 * piece < BM ? p.A : p.W;
-            glds16q(opnd + (src[u] + (unsigned)k0), base + piece * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src[u]), "s"(8 * piece < BM ? abase : wbase), "s"(dst + piece * 1024)
+                         : "memory");
         }
     };
 
