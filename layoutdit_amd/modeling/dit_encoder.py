@@ -74,8 +74,8 @@ class DiTEncoder(nn.Module):
         ``"f32x3"`` / ``"f32x6"``: the fp32 forward with every GEMM operand held as two / three bf16 planes and every product
         formed from three / six plane products on the bf16 MFMA (16x the fp32 matrix rate) with fp32 accumulation; LayerNorm,
         softmax, erf-GELU and the residual stream exactly as ``"f32"``.  ``"f32x6"`` has the error of fp32 arithmetic (6-8e-7 vs
-        float64, under the ``"f32"`` build's own) at 1.3x its speed, ``"f32x3"`` 4.4-5.6e-6 - inside the fp32 build's own parity
-        gates, 180x inside the reference's 1e-3 - at 2.3x (include/ldit.h, LDIT_F32X3).
+        float64, under the ``"f32"`` build's own) at 1.4x its speed, ``"f32x3"`` 4.4-5.6e-6 - inside the fp32 build's own parity
+        gates, 180x inside the reference's 1e-3 - at 2.4-2.5x (include/ldit.h, LDIT_F32X3).
 
         TRAINING (``.train()`` + ``loss.backward()``, ref trainer.py:168-180) is mixed precision for the ``"f32"`` and
         ``"bf16"`` builds alike: bf16 MFMA operands, fp32 accumulation, fp32 residual stream / LayerNorm / softmax /
