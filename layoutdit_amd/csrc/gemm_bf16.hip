@@ -64,6 +64,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
         p.Y = static_cast<float *>(p.Y) + (size_t)split * (size_t)p.M * (size_t)p.ldy;
     }
     const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+    // operand origins in scalar registers, made so HERE (the split-K offset above comes out of a vector-unit division): the DMA's
+    // scalar base is formed from them by scalar adds only, far from this v_readfirstlane (cdna guide 5.7 item 2)
+    const bf16_t *const A_s = uniform_ptr(p.A), *const W_s = uniform_ptr(p.W);
 
     // LDS-DMA roles.  With two waves per SIMD (the 8-wave tiles) only waves 0..3 - one per SIMD - issue DMA pieces, twice as
     // many each; waves 4..7 issue none.  A piece blocks the issuing wave's instruction stream for tens of cycles; with both
@@ -108,8 +111,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
             if (p.x.seg_inner) { const int kb = t / p.x.nseg; seg = t - kb * p.x.nseg; t = kb; }
             else { seg = t / nk; t -= seg * nk; }
         }
-        ka = (unsigned)(((p.x.seg_a >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)t * BKB);
-        kw = (unsigned)(((p.x.seg_w >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)t * BKB);
+        // Made scalar HERE, a k-tile ahead of their use: hipcc evaluates the divisions above on the vector unit, and a v_readfirstlane
+        // result must not reach the LDS-DMA's scalar base within five wait states (cdna guide 5.7 item 2) - issue_range, which only
+        // ADDS these to the kernel-argument pointers on the scalar unit, runs hundreds of instructions later (prologue: s_nop below).
+        ka = __builtin_amdgcn_readfirstlane((unsigned)(((p.x.seg_a >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)t * BKB));
+        kw = __builtin_amdgcn_readfirstlane((unsigned)(((p.x.seg_w >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)t * BKB));
     };
     auto issue_range = [&](int stage, unsigned ka, unsigned kw, int lo, int hi) {
 #ifdef LDIT_BF16_VADDR_DMA           // A/B build only: per-lane 64-bit source addresses through the builtin, as in rounds 1-2
@@ -125,8 +131,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
 #else
         // the k-tile's column offset travels in the scalar base, the lane's row / chunk offset is the kernel constant src[u]
         const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)(smem + stage * (ROWS * ROWB))));
-        // (made scalar by hand: the tile offsets come out of an integer division, which hipcc evaluates on the vector unit)
-        const bf16_t *abase = uniform_ptr(p.A + ka), *wbase = uniform_ptr(p.W + kw);
+        // (scalar arithmetic on kernel-argument pointers and the scalar tile offsets: nothing here comes fresh out of a v_readfirstlane)
+        const bf16_t *abase = A_s + ka, *wbase = W_s + kw;
 #pragma unroll
         for (int u = 0; u < NLW; ++u) {
             if (u < lo || u >= hi) continue;
@@ -179,10 +185,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     // pieces issued in steps 3 / 0 / 1; a SPLIT loader issues all of them right behind the hand-over (twice the pieces: the last
     // ones need the whole k-tile to land)
     constexpr int D3 = SPLIT ? NP : (NP + 2) / 3, D0 = SPLIT ? 0 : (NP - D3 + 1) / 2, D1 = NP - D3 - D0;
-    unsigned ka1, kw1, ka2, kw2;
-    tile_off(0, ka1, kw1);
-    issue_range(0, ka1, kw1, 0, NP);
+    unsigned ka0, kw0, ka1, kw1, ka2, kw2;
+    tile_off(0, ka0, kw0);
     tile_off(1, ka1, kw1);
+    asm volatile("s_nop 4" ::: "memory");                 // the only place where a tile offset is used right after it was made scalar
+    issue_range(0, ka0, kw0, 0, NP);
     issue_range(1, ka1, kw1, 0, D3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tile has landed before anybody reads it
     __syncthreads();

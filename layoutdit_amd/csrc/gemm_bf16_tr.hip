@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
         const int split = tile / ntiles, per = (nk + p.x.splits - 1) / p.x.splits, kt0 = split * per;
         tile -= split * ntiles;
         nk = nk - kt0 < per ? nk - kt0 : per;
-        kbeg = kt0 * BKB;
+        kbeg = __builtin_amdgcn_readfirstlane(kt0 * BKB);      // scalar from here on (the split index comes out of a vector-unit division)
         p.Y = static_cast<float *>(p.Y) + (size_t)split * (size_t)p.M * (size_t)p.ldy;
     }
     const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
@@ -94,8 +94,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
             // every k-tile but a ragged last one: the tile's advance travels in a scalar base, the lane's offset is the kernel
             // constant src[u] (glds16h_sbase, gemm_bf16_common.h) - no vector address arithmetic per piece
             const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)base));
-            const bf16_t *a_k = uniform_ptr(p.A + (unsigned)k0), *a_r = uniform_ptr(p.A + (size_t)k0 * (size_t)p.lda),
-                         *w_r = uniform_ptr(p.W + (size_t)k0 * (size_t)p.ldw);
+            // (k0 is scalar - kbeg was made so at its definition, far from here - so these are scalar-unit arithmetic on kernel-argument
+            // pointers: no v_readfirstlane result reaches the DMA's scalar base within its five wait states, cdna guide 5.7 item 2)
+            const bf16_t *a_k = p.A + (unsigned)k0, *a_r = p.A + (size_t)k0 * (size_t)p.lda, *w_r = p.W + (size_t)k0 * (size_t)p.ldw;
 #pragma unroll
             for (int u = 0; u < NLD; ++u) {
                 const int piece = wave + NWAVES * u;
