@@ -99,10 +99,11 @@ inline Workspace workspace_map(const Geo &g, int batch, int dtype)
     auto take = [&](size_t bytes) { size_t at = o; o += up(bytes, 256); return at; };
     w.h = take(M * g.C * 4);       // residual stream (always fp32)
     if (const size_t S = (size_t)split_planes_of(dtype)) {
-        // split-fp32 builds: y = the S bf16 planes of the LayerNorm / attention output; big = fp32 q|k|v, later the S planes of
-        // the MLP hidden
+        // split-fp32 builds: y = the S bf16 planes of the LayerNorm / attention output; big = the S bf16 planes of q|k|v
+        // ([M, S * 3C], written by EPI_BIAS_SPLIT), later the S planes of the MLP hidden - each sized on its own: nothing
+        // requires F >= 3C
         w.y = take(M * g.C * 2 * S);
-        const size_t qkv = M * 3 * g.C * 4, hid = M * g.F * 2 * S, patches = (size_t)batch * g.P * g.Kp * 2 * S;
+        const size_t qkv = M * 3 * g.C * 2 * S, hid = M * g.F * 2 * S, patches = (size_t)batch * g.P * g.Kp * 2 * S;
         w.big = take(std::max(std::max(qkv, hid), patches));
         w.total = o;
         return w;

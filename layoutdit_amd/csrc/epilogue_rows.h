@@ -30,8 +30,10 @@ enum { EPI_OUT_BF16 = 0, EPI_OUT_FP8 = 1, EPI_OUT_F32 = 2,
 // invariance of the bf16 / fp8 builds).
 // `x` (train step only): bf16 copy of t before GELU / LayerScale (Ypre), per-row factor on lam (rowscale), pre-activation of
 // the GELU derivative (aux).
-template <int TM, int TN, int EPI, int OUT>
-__device__ __forceinline__ void store_rows_via_lds(const f32x16 (&acc)[TM][TN], char *buf, void *Yv, float *Y2, const float *R,
+// L16: the accumulators are 2 TM x 2 TN tiles of 16 x 16 (v_mfma_f32_16x16x32_*: acc[i][j][e] = row 16 i + (lane & 15), column
+// 16 j + 4 (lane >> 4) + e) instead of TM x TN tiles of 32 x 32; only the write into the slab differs.
+template <int TM, int TN, int EPI, int OUT, bool L16 = false, typename ACC>
+__device__ __forceinline__ void store_rows_via_lds(const ACC &acc, char *buf, void *Yv, float *Y2, const float *R,
                                                    const float *bias, const float *lam, const float *wscale, int ldy, int mw,
                                                    int nw, int lane, float ab, float oinv, const GemmExtra x = GemmExtra{})
 {
@@ -52,6 +54,16 @@ __device__ __forceinline__ void store_rows_via_lds(const f32x16 (&acc)[TM][TN], 
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            if constexpr (L16) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const f32x4 v = {acc[2 * i + ii][4 * jp + jj][0], acc[2 * i + ii][4 * jp + jj][1], acc[2 * i + ii][4 * jp + jj][2],
+                                         acc[2 * i + ii][4 * jp + jj][3]};
+                        *reinterpret_cast<f32x4 *>(buf + (16 * ii + (lane & 15)) * EPI_ROW_BYTES + (16 * jj + 4 * (lane >> 4)) * 4) = v;
+                    }
+            } else {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -60,6 +72,7 @@ __device__ __forceinline__ void store_rows_via_lds(const f32x16 (&acc)[TM][TN], 
                                      acc[i][2 * jp + jj][4 * g + 3]};
                     *reinterpret_cast<f32x4 *>(buf + c32 * EPI_ROW_BYTES + (32 * jj + 8 * g + 4 * h) * 4) = v;
                 }
+            }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int row = 4 * r + rrow;

@@ -19,9 +19,9 @@
 #include "gemm_bf16_common.h"
 
 #ifdef LDIT_GEMM_STAMPS
-// diagnostic build only (make dbg; scripts/gemm_bf16_stamps.py): per-workgroup cycles of wave 0 in gemm_bf16_mfma -
-// 4 x int64: k-loop total, of which waiting for its own DMA (vmcnt) at the hand-over, of which waiting at the barrier,
-// epilogue
+// diagnostic build only (make dbg; scripts/gemm_bf16_stamps.py): per-workgroup cycles of wave 0 (a loader) and of wave NWAVES / 2
+// (its SIMD partner) in gemm_bf16_mfma - 2 x 8 x int64: k-loop total, of which waiting for its own DMA (vmcnt) at the hand-over, of
+// which waiting at the barrier, epilogue, kernel entry -> k-loop, k-loop in s_memrealtime ticks (100 MHz: the in-kernel clock)
 __device__ unsigned long long *g_gemm_bf16_stamps = nullptr;
 #endif
 
@@ -39,11 +39,18 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, ROWS = BM + BN;
     static_assert(BM % 8 == 0, "a DMA piece is eight rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifndef LDIT_BF16_MFMA32
+    constexpr bool L16 = true;       // v_mfma_f32_16x16x32_bf16 (default)
+#else
+    constexpr bool L16 = false;      // A/B build: v_mfma_f32_32x32x16_bf16, as rounds 1-3 (same bits)
+#endif
 
+#ifdef LDIT_GEMM_STAMPS
+    const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int c32 = lane & 31, h = lane >> 5;
 
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
     const int ntiles = nbm * nbn, nblocks = ntiles * p.x.splits;
@@ -81,10 +88,18 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
 #else
     constexpr bool SPLIT = NWAVES == 8 && !(TM == 5 && (EPI == EPI_SCALE_RESID || EPI == EPI_F32 || EPI == EPI_EMBED));
 #endif
+#ifdef LDIT_BF16_STAGGER
+    // A/B build: all eight waves issue (half the pieces each); waves 0..3 right behind the hand-over, waves 4..7 - their SIMD
+    // partners - a step or two later: one wave of a SIMD multiplies while the other is held up by its pieces
+    constexpr bool STAGGER = SPLIT;
+    constexpr int LW = NWAVES;
+#else
+    constexpr bool STAGGER = false;
     constexpr int LW = SPLIT ? NWAVES / 2 : NWAVES;      // waves that issue
+#endif
     constexpr int NLW = ROWS / (8 * LW);                 // pieces per issuing wave and k-tile
     static_assert(ROWS % (8 * LW) == 0, "DMA pieces must split evenly over the issuing waves");
-    const bool loader = !SPLIT || wave < LW;             // wave-uniform
+    const bool loader = !SPLIT || STAGGER || wave < LW;  // wave-uniform
     unsigned src[NLW];   // element (bf16) offsets
 #pragma unroll
     for (int u = 0; u < NLW; ++u) {
@@ -142,6 +157,43 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
 #endif
     };
 
+#ifndef LDIT_BF16_MFMA32
+    // v_mfma_f32_16x16x32_bf16 build: the same LDS image, a 32 x 32 tile = 2 x 2 tiles of 16 x 16, lane (r16, q) supplies the 8
+    // consecutive k of chunk q (of the four of a 32-deep step) for row r16 - ONE ds_read_b128 per 16-row fragment and 32-deep step.
+    // A k-tile is four HALF steps: (k32, half) = (0, a) (0, b) (1, a) (1, b); a half multiplies TM of the 2 TM activation
+    // fragments with all 2 TN weight fragments (16 MFMAs of 16 cycles for the 128 x 64 wave tile = the 8 x 32 cycles of a 16-deep
+    // step of the 32x32x16 build).  MI355X_MICROARCH.md, DVFS give-back item 7: this shape holds a higher clock on random data.
+    f32x4 acc[2 * TM][2 * TN];
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0f;
+    const int r16 = lane & 15, q16 = lane >> 4;
+    const int sw = (r16 >> 1) & 7;
+    const int a_row = (wm * TM * 32 + r16) * ROWB, b_row = (BM + wn * TN * 32 + r16) * ROWB;
+    // activation fragments of half `hf` (fragments hf * TM .. hf * TM + TM - 1) of 32-deep step k32
+    auto load_a = [&](int stage, int k32, int hf, bf16x8(&xa)[TM]) {
+        const char *base = smem + stage * (ROWS * ROWB) + ((k32 * 4 + q16) ^ sw) * 16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const bf16x8 *>(base + a_row + (hf * TM + i) * 16 * ROWB);
+    };
+    auto load_w = [&](int stage, int k32, bf16x8(&wb)[2 * TN]) {
+        const char *base = smem + stage * (ROWS * ROWB) + ((k32 * 4 + q16) ^ sw) * 16;
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j) wb[j] = *reinterpret_cast<const bf16x8 *>(base + b_row + j * 16 * ROWB);
+    };
+    auto mfma_half = [&](int hf, const bf16x8(&xa)[TM], const bf16x8(&wb)[2 * TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 * TN; ++j) {
+                if (hf == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+                else acc[TM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[TM + i][j], 0, 0, 0);
+            }
+    };
+#else
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -150,6 +202,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    const int c32 = lane & 31, h = lane >> 5;
     const int sw = (c32 >> 1) & 7;
     const int a_row = (wm * TM * 32 + c32) * ROWB, b_row = (BM + wn * TN * 32 + c32) * ROWB;
     auto load_frags = [&](int stage, int s, bf16x8(&xa)[TM], bf16x8(&wb)[TN]) {
@@ -167,17 +220,106 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
     };
 
+#endif
+
     // Pinned pipeline (sched_group_barrier), four 16-deep steps per 64-deep k-tile:
     //   step s multiplies fragments read during step s-1 while the fragments of step s+1 are read, ONE LDS read or DMA
     //   piece per MFMA;  the hand-over barrier (tile kt+1 landed, stage cur released) sits in front of step 3's MFMAs;
     //   the NLD DMA pieces of a tile are spread over step 3 of the previous iteration (right after the hand-over that
     //   freed their stage) and steps 0 and 1, so the last of them still has ~2 steps of MFMA time to land.
     constexpr int SG_MFMA = 0x8, SG_VMEM = 0x20, SG_DSR = 0x100;
+#ifndef LDIT_BF16_MFMA32
+    constexpr int NM = 2 * TM * TN;                     // MFMAs per half step
+    bf16x8 xaA[TM], xaB[TM], wbX[2 * TN], wbY[2 * TN];
+#ifdef LDIT_GEMM_STAMPS
+    unsigned long long st_vm = 0, st_bar = 0, st_loop0 = 0, st_real0 = 0;
+#endif
+    // one half step's schedule: `nr` LDS reads and `nd` DMA pieces dealt between its NM MFMAs, one per MFMA
+    auto deal = [&](auto nr_c, auto nd_c, auto id_c) {
+        constexpr int NR = decltype(nr_c)::value, ND = decltype(nd_c)::value, ID = decltype(id_c)::value;
+        static_assert(NR + ND <= NM, "more reads and pieces than MFMAs in a half step");
+#pragma unroll
+        for (int g = 0; g < NR; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, ID);
+            __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, ID);
+        }
+#pragma unroll
+        for (int g = 0; g < ND; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, ID);
+            __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, ID);
+        }
+        if (NM - NR - ND > 0) __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NR - ND, ID);
+    };
+    auto kloop = [&](auto np_c, auto late_c) {
+    constexpr int NP = decltype(np_c)::value;
+    constexpr int LATE = decltype(late_c)::value;        // 0: pieces dealt as always; 1 / 2: all of them in half step (0, a) / (0, b)
+    constexpr int D3 = LATE ? 0 : (SPLIT ? NP : (NP + 2) / 3), D0 = LATE == 1 ? NP : LATE == 2 ? 0 : (SPLIT ? 0 : (NP - D3 + 1) / 2), D1 = NP - D3 - D0;
+    unsigned ka0, kw0, ka1, kw1, ka2, kw2;
+    tile_off(0, ka0, kw0);
+    tile_off(1, ka1, kw1);
+    asm volatile("s_nop 4" ::: "memory");
+    issue_range(0, ka0, kw0, 0, NP);
+    issue_range(1, ka1, kw1, 0, D3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#ifdef LDIT_GEMM_STAMPS
+    st_loop0 = __builtin_amdgcn_s_memtime();
+    st_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    load_a(0, 0, 0, xaA);
+    load_w(0, 0, wbX);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        tile_off(kt + 2, ka2, kw2);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- half step (0, a): reads the activation fragments of (0, b)
+        load_a(cur, 0, 1, xaB);
+        issue_range(cur ^ 1, ka1, kw1, D3, D3 + D0);
+        mfma_half(0, xaA, wbX);
+        deal(std::integral_constant<int, TM>{}, std::integral_constant<int, (D0 < NM - TM ? D0 : NM - TM)>{}, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- (0, b): reads all fragments of (1, a)
+        load_a(cur, 1, 0, xaA);
+        load_w(cur, 1, wbY);
+        issue_range(cur ^ 1, ka1, kw1, D3 + D0, NP);
+        mfma_half(1, xaB, wbX);
+        deal(std::integral_constant<int, TM + 2 * TN>{}, std::integral_constant<int, (D1 < NM - TM - 2 * TN ? D1 : NM - TM - 2 * TN)>{}, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- (1, a): reads the activation fragments of (1, b)
+        load_a(cur, 1, 1, xaB);
+        mfma_half(0, xaA, wbY);
+        deal(std::integral_constant<int, TM>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- hand-over
+#ifdef LDIT_GEMM_STAMPS
+        {
+            const unsigned long long h0 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long h1 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const unsigned long long h2 = __builtin_amdgcn_s_memtime();
+            st_vm += h1 - h0; st_bar += h2 - h1;
+        }
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#endif
+        // ---- (1, b): MFMAs of the last fragments | first fragments of tile kt+1 | first DMA pieces of tile kt+2 -> stage cur
+        load_a(cur ^ 1, 0, 0, xaA);
+        load_w(cur ^ 1, 0, wbX);
+        issue_range(cur, ka2, kw2, 0, D3);
+        ka1 = ka2; kw1 = kw2;
+        mfma_half(1, xaB, wbY);
+        deal(std::integral_constant<int, TM + 2 * TN>{}, std::integral_constant<int, (D3 < NM - TM - 2 * TN ? D3 : NM - TM - 2 * TN)>{}, std::integral_constant<int, 3>{});
+    }
+    };
+#else
     constexpr int NM = TM * TN, NF = TM + TN;
     static_assert(NF <= NM, "fewer MFMAs than fragment reads per step");
     bf16x8 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
 #ifdef LDIT_GEMM_STAMPS
-    unsigned long long st_vm = 0, st_bar = 0, st_loop0 = 0;
+    unsigned long long st_vm = 0, st_bar = 0, st_loop0 = 0, st_real0 = 0;
 #endif
     // the k-loop, instantiated per role: NP = DMA pieces this wave issues per k-tile (0 for the non-loaders of a SPLIT tile)
     auto kloop = [&](auto np_c) {
@@ -195,6 +337,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     __syncthreads();
 #ifdef LDIT_GEMM_STAMPS
     st_loop0 = __builtin_amdgcn_s_memtime();
+    st_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
     load_frags(0, 0, xa0, wb0);
     for (int kt = 0; kt < nkt; ++kt) {
@@ -278,28 +421,39 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
         if (NM - NF - D3 > 0) __builtin_amdgcn_sched_group_barrier(SG_MFMA, NM - NF - D3, 3);
     }
     };
+#endif
+#ifndef LDIT_BF16_MFMA32
+#ifndef LDIT_BF16_STAGGER_STEP
+#define LDIT_BF16_STAGGER_STEP 2
+#endif
+    if (STAGGER && wave >= NWAVES / 2) kloop(std::integral_constant<int, NLW>{}, std::integral_constant<int, LDIT_BF16_STAGGER_STEP>{});
+    else if (loader) kloop(std::integral_constant<int, NLW>{}, std::integral_constant<int, 0>{});
+    else kloop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+#else
     if (loader) kloop(std::integral_constant<int, NLW>{});
     else kloop(std::integral_constant<int, 0>{});
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches of the tail must not outlive the LDS allocation
 #ifdef LDIT_GEMM_STAMPS
-    asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][15]));
-    const unsigned long long st_loop1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[(L16 ? 2 : 1) * TM - 1][(L16 ? 2 : 1) * TN - 1][L16 ? 3 : 15]));
+    const unsigned long long st_loop1 = __builtin_amdgcn_s_memtime(), st_real1 = __builtin_amdgcn_s_memrealtime();
 #endif
 
     const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
     if (cols_in && m0 + BM <= p.M && !p.direct_epi) {
         __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
-        store_rows_via_lds<TM, TN, EPI, f32_out<EPI>() ? EPI_OUT_F32 : (EPI == EPI_GELU_SPLIT || EPI == EPI_BIAS_SPLIT) ? EPI_OUT_SPLIT : EPI_OUT_BF16>(
+        store_rows_via_lds<TM, TN, EPI, f32_out<EPI>() ? EPI_OUT_F32 : (EPI == EPI_GELU_SPLIT || EPI == EPI_BIAS_SPLIT) ? EPI_OUT_SPLIT : EPI_OUT_BF16, L16>(
             acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, nullptr, p.ldy, mw, nw, lane, 1.0f, 1.0f, p.x);
-    } else if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0>(p, acc, mw, nw, lane);
-    else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
-    else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
+    } else if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0, L16>(p, acc, mw, nw, lane);
+    else if (cols_in) store_h<TM, TN, EPI, 1, L16>(p, acc, mw, nw, lane);
+    else store_h<TM, TN, EPI, 2, L16>(p, acc, mw, nw, lane);
 #ifdef LDIT_GEMM_STAMPS
-    if (g_gemm_bf16_stamps && wave == 0 && lane == 0) {
+    if (g_gemm_bf16_stamps && (wave == 0 || wave == NWAVES / 2) && lane == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long *d = g_gemm_bf16_stamps + (size_t)blockIdx.x * 4;
+        unsigned long long *d = g_gemm_bf16_stamps + (size_t)blockIdx.x * 16 + (wave == 0 ? 0 : 8);
         d[0] = st_loop1 - st_loop0; d[1] = st_vm; d[2] = st_bar; d[3] = __builtin_amdgcn_s_memtime() - st_loop1;
+        d[4] = st_loop0 - st_entry; d[5] = st_real1 - st_real0;
     }
 #endif
 }

@@ -63,32 +63,38 @@ template <int EPI> constexpr bool f32_out() { return EPI == EPI_SCALE_RESID || E
 // MODE 0: tile inside the matrix, 16-B / 8-B accesses unchecked; MODE 1: columns inside, rows past M skipped (the ragged
 // last row tile keeps its vector accesses - a lane owns a row, so the element-wise path does not coalesce and cost ~20 us);
 // MODE 2: element-wise with checks.
-template <int TM, int TN, int EPI, int MODE>
-__device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane)
+// L16: the accumulators are 2 TM x 2 TN tiles of 16 x 16 (v_mfma_f32_16x16x32_bf16: acc[i][j][e] = row 16 i + (lane & 15), column
+// 16 j + 4 (lane >> 4) + e): per 32 x 32 block a lane then owns two rows x two column quads instead of one row x four quads.  The
+// arithmetic per element is the same statement either way (same bits).
+template <int TM, int TN, int EPI, int MODE, bool L16 = false, typename ACC>
+__device__ __forceinline__ void store_h(const GemmArgsH &p, const ACC &acc, int mw, int nw, int lane)
 {
-    const int c32 = lane & 31, h = lane >> 5;
+    constexpr int NQ = L16 ? 2 : 4, NR = L16 ? 2 : 1;      // column quads per row, rows - per lane and 32 x 32 block
+    const int row_in = L16 ? (lane & 15) : (lane & 31), quad_in = L16 ? 4 * (lane >> 4) : 4 * (lane >> 5);
+    constexpr int QSTEP = L16 ? 16 : 8;
     const bool dual = p.Y2 != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        f32x4 bias[4], lam[4];
+        f32x4 bias[NQ], lam[NQ];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < NQ; ++g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int n = nw + j * 32 + 8 * g + 4 * h + e;
+                const int n = nw + j * 32 + QSTEP * g + quad_in + e;
                 const bool ok = MODE != 2 || n < p.N;
                 bias[g][e] = (ok && p.bias) ? p.bias[n] : 0.0f;
                 lam[g][e] = (EPI == EPI_SCALE_RESID && ok) ? p.lam[n] : 0.0f;
             }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = mw + i * 32 + c32;
+        for (int ir = 0; ir < TM * NR; ++ir) {
+            const int i = ir / NR, rr = ir % NR;
+            const int m = mw + i * 32 + 16 * rr + row_in;
             if (MODE != 0 && m >= p.M) continue;
-            f32x4 res[4];
+            f32x4 res[NQ];
             if (EPI == EPI_SCALE_RESID) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = nw + j * 32 + 8 * g + 4 * h;
+                for (int g = 0; g < NQ; ++g) {
+                    const int n = nw + j * 32 + QSTEP * g + quad_in;
                     const unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
                     if (MODE != 2) res[g] = *reinterpret_cast<const f32x4 *>(p.R + o);
                     else
@@ -100,12 +106,15 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const f32x16 (&acc)[
             const float rs = (EPI == EPI_SCALE_RESID && p.x.rowscale) ? p.x.rowscale[m] : 1.0f;
             const unsigned img = EPI == EPI_EMBED ? (unsigned)m / (unsigned)p.x.patches : 0u;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nw + j * 32 + 8 * g + 4 * h;
+            for (int g = 0; g < NQ; ++g) {
+                const int n = nw + j * 32 + QSTEP * g + quad_in;
                 unsigned o = (unsigned)m * (unsigned)p.ldy + (unsigned)n;
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bias[g][e];
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (L16) v[e] = acc[2 * i + rr][2 * j + g][e] + bias[g][e];
+                    else v[e] = acc[i][j][4 * g + e] + bias[g][e];
+                }
                 if (EPI == EPI_EMBED) {
                     // token row of patch row m (one CLS slot in front of every image) + its position row, as the slab epilogue
                     const float *pq = p.x.pos + (((unsigned)m - img * (unsigned)p.x.patches + 1u) * (unsigned)p.ldy + (unsigned)n);

@@ -103,7 +103,7 @@ class _FPNFn(torch.autograd.Function):
         ctx.inners = None
         B, T, Cc = toks[0].shape
         Ch = lw[0].shape[0]
-        need = ctx.needs_input_grad[1:]
+        need = ctx.needs_input_grad[1:]                              # lines up with ``args``: t0..t3, (lw, lb) x 4, (cw, cb) x 4
         d_inner = [None] * 4
         g_cw, g_cb = [None] * 4, [None] * 4
         for i in range(4):                                            # finest first: the top-down adjoint flows fine -> coarse
@@ -114,9 +114,9 @@ class _FPNFn(torch.autograd.Function):
                 dy = dy.float() if dy.dtype != torch.float32 else dy
                 dy = dy.contiguous()                                  # NHWC [B, h, w, Ch]; a no-op for channels-last gradients
                 d_inner[i] = ops.conv3x3_nhwc(dy, _flip_ihwo(cw[i]))                    # dgrad: same GEMM, flipped weight
-                if need[13 + 2 * i - 1]:
+                if need[13 + 2 * i]:
                     g_cb[i] = ops.colsum(dy.view(B * h * w, Ch))
-                if need[12 + 2 * i - 1]:
+                if need[12 + 2 * i]:
                     slack = w + 3
                     dy_p = ops.pad_nhwc_bf16(dy)                                         # [B (h+2)(w+2), Ch]
                     in_p = ops.pad_nhwc_bf16(inners[i], slack_rows=slack)
@@ -138,9 +138,9 @@ class _FPNFn(torch.autograd.Function):
             d_lat = ops.fpn_merge_bwd(d_inner[i], gh, gw, scales[i])                     # [B, T, Ch], CLS row zero
             d_inner[i] = None
             d2 = d_lat.view(B * T, Ch)
-            if need[5 + 2 * i - 1]:
+            if need[5 + 2 * i]:
                 g_lb[i] = ops.colsum(d2)
-            if need[4 + 2 * i - 1]:
+            if need[4 + 2 * i]:
                 g_lw[i] = ops.wgrad_bf16(ops.cast_bf16(d2), ops.cast_bf16(toks[i].view(B * T, Cc)), B * T).view(Ch, Cc, 1, 1)
             if need[i]:
                 wt = lw[i].reshape(Ch, Cc).t().contiguous()                              # [C, Ch]: the dgrad's K-contiguous operand

@@ -55,6 +55,30 @@ def test_sizing_is_host_side_and_consistent():
     assert lib.ldit_workspace_bytes(C.byref(lc), 0) == 0
 
 
+@pytest.mark.parametrize("dtype,S", [(_lib.DTYPE_F32X3, 2), (_lib.DTYPE_F32X6, 3), (_lib.DTYPE_F32, 0), (_lib.DTYPE_BF16, 0)])
+@pytest.mark.parametrize("mlp_ratio", [2, 4])
+def test_workspace_covers_every_region_the_forward_addresses(dtype, S, mlp_ratio):
+    """ldit_workspace_bytes against the buffers ldit_vit_forward writes (csrc/api.hip): the residual stream, the LayerNorm /
+    attention output, and `big` = q|k|v then the MLP hidden.  An mlp narrower than 3 * hidden passes validation (F % 64 only),
+    and in the split builds q|k|v leave their GEMM as S bf16 planes [M, S * 3C] - ADVICE r3: `big` was sized for fp32 q|k|v
+    (12 M C bytes) while f32x6 writes 18 M C."""
+    lib = _lib.load()
+    base = cfgs.vit_base()
+    base.intermediate_size = mlp_ratio * base.hidden_size
+    lc = _cfg(base)
+    lc.dtype = dtype
+    B = 3
+    M, Cc, Fm = B * 197, base.hidden_size, base.intermediate_size
+    if S:
+        y, qkv, hid = M * Cc * 2 * S, M * 3 * Cc * 2 * S, M * Fm * 2 * S
+    else:
+        act = 4 if dtype == _lib.DTYPE_F32 else 2
+        y, qkv, hid = M * Cc * act, M * 3 * Cc * act, M * Fm * act
+    need = M * Cc * 4 + y + max(qkv, hid)
+    got = lib.ldit_workspace_bytes(C.byref(lc), B)
+    assert got >= need, (got, need)
+
+
 @pytest.mark.parametrize("mutate,fragment", [
     (lambda c: setattr(c, "heads", 7), "divisible"),
     (lambda c: setattr(c, "heads", 24), "head_dim"),

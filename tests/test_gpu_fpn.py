@@ -210,6 +210,64 @@ def test_dit_with_fpn_trains_like_the_reference(enc_dtype):
         sum((f * torch.from_numpy(ws[k]).to(DEV)).sum() for k, f in feats.items()).backward()
 
 
+@pytest.mark.parametrize("case", ["frozen_encoder", "fp8_encoder", "one_fpn_parameter_frozen"])
+def test_fpn_parameter_gradients_follow_their_own_requires_grad_flag(case):
+    """The reference's commented option (ref dit_backbone.py:74-76: backbone frozen, FPN + head trained) and a single frozen FPN
+    parameter: every parameter that still requires a gradient gets one, equal to the float64 oracle's, and a frozen one gets
+    none (the flags used to be read one slot off, so the neighbour's flag decided)."""
+    cfg = cfgs.vit_micro()
+    cfg.drop_path_rate = 0.0
+    cfg.taps = [1, 1, 2, 3]
+    w = synth.synth_weights(cfg, 3)
+    B, size, g = 2, 64, 4
+    x = synth.synth_images(B, size, size, seed=5, kind="uniform")
+    torch.manual_seed(0)
+    m = DiTWithFPN(config=cfg, compute_dtype="fp8" if case == "fp8_encoder" else "f32")
+    m.backbone.dit.load_numpy(w)
+    with torch.no_grad():
+        for p in m.fpn.parameters():
+            if p.dim() == 1:
+                p.normal_(0.0, 0.05)
+    m = m.to(DEV)
+    frozen = set()
+    if case == "one_fpn_parameter_frozen":
+        m.train()
+        frozen = {"inner_blocks.1.0.weight"}
+        m.fpn.inner_blocks[1][0].weight.requires_grad_(False)
+    else:
+        for p in m.backbone.parameters():
+            p.requires_grad_(False)
+        if case == "fp8_encoder":
+            m.eval()                                          # an inference-only build behind a trainable FPN
+            m.backbone.dit.calibrate_fp8(torch.from_numpy(x).to(DEV))
+        else:
+            m.backbone.eval()
+    xt = torch.from_numpy(x).to(DEV)
+    feats = m(xt)
+    ws = {k: _rand(80 + i, *f.shape, scale=1.0 / np.sqrt(f.numel())) for i, (k, f) in enumerate(feats.items())}
+    sum((f * torch.from_numpy(ws[k]).to(DEV)).sum() for k, f in feats.items()).backward()
+    torch.cuda.synchronize()
+    # the oracle differentiates the FPN at the taps the build itself produced (the encoder's own parity is tested elsewhere)
+    with torch.no_grad():
+        hs = m.backbone.dit(xt, taps=m.backbone.layer_idxs).hidden_states
+    taps_t = [hs[i].detach().cpu().double() for i in m.backbone.layer_idxs]
+    wt = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in _fpn_weights(m).items()}
+    ref = fpn_forward_t(backbone_maps_t(taps_t, g, g), wt)
+    sum((ref[k] * torch.from_numpy(ws[k]).double()).sum() for k in ref).backward()
+    tol = 3e-2
+    for k, r in wt.items():
+        got = dict(m.fpn.named_parameters())[k].grad
+        if k in frozen:
+            assert got is None, k
+            continue
+        assert got is not None, f"{k}: no gradient although it requires one"
+        assert rel_l2(got.cpu().numpy(), r.grad.numpy()) < tol, k
+    if case == "one_fpn_parameter_frozen":
+        assert m.backbone.dit._flat_state.named[4][1].grad is not None
+    else:
+        assert all(p.grad is None for p in m.backbone.parameters())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_detector_input_transform_ragged_list(dtype):
     """ref model.py:45-55,87-88: List[Tensor[3, h, w]] in [0, 1] -> normalised 224 x 224 batch; boxes follow the resize."""
