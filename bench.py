@@ -10,8 +10,9 @@
     2  ViT-B/16 224x224 bs=64/GPU bf16 train step: forward + backward + gradient all-reduce (RCCL, N > 1) + fused AdamW
     3  ViT-L/16 512x512 bs=16/GPU bf16 forward (N = 1025 tokens)
     4  ViT-B/16 224x224 bs=32/GPU fp8 forward (bs=256 over 8 GPUs)
-    5  config 1 on the split-fp32 build "f32x3" (every GEMM = three bf16-plane products on the bf16 MFMA, fp32 everything else)
-    6  config 1 on "f32x6" (six plane products: the error of fp32 arithmetic)
+    5  (not a BASELINE config) config 1's workload on the split-fp32 build "f32x3" (every GEMM = three bf16-plane products on the
+       bf16 MFMA, fp32 everything else)
+    6  (not a BASELINE config) config 1's workload on "f32x6" (six plane products: the error of fp32 arithmetic)
 (`--model/--size/--batch/--dtype` still override single fields for experiments.)
 
 With `--gpus N > 1` and no WORLD_SIZE in the environment the script launches itself: the parent process (which never
@@ -24,7 +25,7 @@ barrier + synchronize brackets (max over ranks); rank 0 prints ONE JSON line.  E
                  same timed region
   roofline     - the dominant kernel family (the MFMA GEMMs): algorithmic FLOPs / HIP-event time per launch, measured live
                  in a second K-step pass with events on the launch stream, against the dense MFMA peak of the dtype;
-                 `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_traffic.json,
+                 `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r0N_traffic.json,
                  labelled with the commit they were collected on) or null
   split_fp32   - (N = 1, config 1 only) the SAME workload on the two split-fp32 builds, measured in the same process right after the
                  headline: images/sec, ms per step, and the relative-L2 distance of every tap from the headline (fp32 MFMA) build's
@@ -63,7 +64,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="BASELINE.json configs[i]")
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS),
+                    help="1..4 = BASELINE.json configs[i]; 5 / 6 = configs[1]'s workload on the f32x3 / f32x6 split-fp32 builds")
     ap.add_argument("--model", default=None, choices=["micro", "tiny", "base", "large"])
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "fp8", "f32x3", "f32x6"])
@@ -154,13 +156,14 @@ def pmc_traffic(args):
     """HBM bytes per GEMM launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
     process), with the commit they were measured on.  Only for the exact workload they were collected on; else null."""
     key = f"{args.mode}:{args.model}:{args.size}:{args.batch}:{args.dtype}"
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
-            rec = json.load(f).get(key)
-        if rec:
-            return round(rec["gemm_hbm_bytes_per_launch"]), f"profiles/r03_traffic.json[{key}] profiled@{rec['commit']}"
-    except (OSError, KeyError, ValueError):
-        pass
+    for name in ("r04_traffic.json", "r03_traffic.json"):       # newest committed PMC passes first
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f).get(key)
+            if rec:
+                return round(rec["gemm_hbm_bytes_per_launch"]), f"profiles/{name}[{key}] profiled@{rec['commit']}"
+        except (OSError, KeyError, ValueError):
+            pass
     return None, None
 
 
@@ -269,6 +272,21 @@ def percentiles(ms):
             "p90": round(float(np.percentile(a, 90)), 4), "source": "HIP events on the launch stream, one pair per step"}
 
 
+def per_rank_report(rows):
+    """rows[k] = [images/s, GEMM-family roofline fraction (nan when the roofline pass was skipped), ms per step] of rank k, each from
+    that rank's OWN clock and HIP events -> the "MFMA util % at 1/2/4/8 GPU" half of BASELINE.json's metric: min / mean / max over
+    the ranks and the per-rank lists, so a slow rank shows (the headline `value` only sees it through the max-over-ranks time)."""
+    import math
+
+    def stats(col):
+        v = [row[col] for row in rows if not math.isnan(row[col])]
+        if not v:
+            return None
+        return {"min": round(min(v), 4), "mean": round(sum(v) / len(v), 4), "max": round(max(v), 4), "per_rank": [round(x, 4) for x in v]}
+    return {"images_per_sec": stats(0), "gemm_mfma_roofline_frac": stats(1), "ms_per_step": stats(2), "ranks": len(rows),
+            "source": "each rank's own wall clock between the barriers and its own HIP-event GEMM time"}
+
+
 # ---- one rank ----------------------------------------------------------------------------------------------------------------
 def run_rank(args) -> None:
     import torch
@@ -283,8 +301,10 @@ def run_rank(args) -> None:
         r = dp.init(backend="gloo")
         dp.barrier(r)
         worst = dp.max_over_ranks(r, float(r.rank + 1))
+        # the per-rank report of the real run, on made-up numbers: rank k "measured" 100 (k + 1) images/s at MFMA fraction 0.1 (k + 1)
+        per = per_rank_report(dp.gather_over_ranks(r, [100.0 * (r.rank + 1), 0.1 * (r.rank + 1), 5.0 + r.rank]))
         if r.is_main:
-            print(json.dumps({"dryrun": True, "n_gpus": r.world, "max_over_ranks": worst, "gpus_arg": args.gpus}), flush=True)
+            print(json.dumps({"dryrun": True, "n_gpus": r.world, "max_over_ranks": worst, "gpus_arg": args.gpus, "per_rank": per}), flush=True)
         dp.finalize(r)
         return
     r = dp.init()
@@ -348,6 +368,14 @@ def run_rank(args) -> None:
                     model(x, _timing=timing)
         torch.cuda.synchronize(dev)
 
+    # every rank: its own throughput (own clock) and its own GEMM-family roofline fraction (own HIP events), gathered to rank 0
+    mult_r = 3 if train else 1
+    own_frac = float("nan")
+    if timing and timing.get("gemm_ms"):
+        own_frac = (gemm_flops_per_image(cfg, args.size) * mult_r * args.batch * args.steps / (timing["gemm_ms"] * 1e-3) / 1e12
+                    / PEAK_TFLOPS[args.dtype])
+    per_rank = dp.gather_over_ranks(r, [args.batch * args.steps / (t1 - t0), own_frac, 1e3 * (t1 - t0) / args.steps])
+
     if r.is_main:
         headline = (args.model, args.size, args.batch, args.dtype, args.mode) == ("base", 224, 64, "f32", "forward")
         images = args.batch * r.world * args.steps
@@ -361,7 +389,8 @@ def run_rank(args) -> None:
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"ViT-{args.model}/16 {args.size}x{args.size} bs={args.batch} {args.dtype} "
                                    f"{'forward' if not train else 'train step'}, taps {cfg.taps} "
-                                   f"(BASELINE.json configs[{args.config}])",
+                                   + (f"(BASELINE.json configs[{args.config}])" if args.config <= 4 else
+                                      f"(BASELINE.json configs[1] workload on the {args.dtype} split-fp32 build - not a BASELINE config)"),
                        "images_per_gpu": args.batch, "global_batch": args.batch * r.world,
                        "parallelism": f"dp{r.world}: batch-sharded replicas, "
                                       + ("bucketed gradient all-reduce (one bucket per layer) overlapped with backward"
@@ -385,11 +414,12 @@ def run_rank(args) -> None:
                                 "traffic_source": source,
                                 "kernel": "fp32 MFMA GEMM family (patch-embed, qkv, o_proj, fc1, fc2)" if args.dtype == "f32"
                                 else f"bf16 MFMA GEMM family on split fp32 operands ({args.dtype}: peak = 2.5 PF / plane products per fp32 "
-                                     f"product; patch-embed stays on the fp32 MFMA)" if args.dtype.startswith("f32x") else f"{args.dtype} MFMA GEMM family (qkv, o_proj, fc1, fc2"
-                                     + (" + their dgrad / wgrad" if train else "") + "; patch-embed stays fp32)",
+                                     f"product; patch-embed on plane products too)" if args.dtype.startswith("f32x") else f"{args.dtype} MFMA GEMM family (qkv, o_proj, fc1, fc2"
+                                     + (" + their dgrad / wgrad" if train else "") + "; patch-embed = bf16 im2col pass + bf16 MFMA GEMM)",
                                 "launches": n, "avg_launch_ms": round(timing["gemm_ms"] / n, 5),
                                 "flops_per_launch": gemm_flops // n}
             line["kernel_ms_per_step"] = {k[:-3]: round(v / args.steps, 4) for k, v in timing.items() if k.endswith("_ms")}
+        line["per_rank"] = per_rank_report(per_rank)
         if r.world == 1 and headline and not args.no_split_fp32:
             line["split_fp32"] = split_fp32_lines(cfg, weights, x, out, args.steps, args.warmup, dev)
         if r.world == 1 and args.cpu_sample > 0 and headline:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LDIT_ABI_VERSION 4
+#define LDIT_ABI_VERSION 5
 #define LDIT_MAX_TAPS 8
 
 enum ldit_status {
@@ -152,6 +152,16 @@ size_t ldit_workspace_bytes(const ldit_cfg *cfg, int32_t batch);
 int ldit_vit_forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batch, void *const *tap_out,
                      void *workspace, size_t workspace_bytes, ldit_stream stream);
 
+/* The same forward fed by the detector's image list BEFORE its input transform (ref src/layoutdit/modeling/model.py:50-54:
+ * GeneralizedRCNNTransform, fixed_size = (img_h, img_w) of cfg, image_mean = image_std = 0.5): `images` / `heights` / `widths` are
+ * HOST arrays of `batch` entries (device pointers to [in_ch, h_i, w_i] planar images in [0, 1]; half_in != 0: fp16).  In the bf16 /
+ * fp8 / split-fp32 builds the pass that writes the patch-embedding operand evaluates (bilinear(img) - mean) / std itself - no fp32
+ * batch is materialised; the fp32 build, whose GEMM gathers pixels by LDS-DMA, produces the batch in its workspace first.  Either
+ * way the taps EQUAL ldit_preprocess_* followed by ldit_vit_forward (one shared statement, csrc/image_blend.h). */
+int ldit_vit_forward_images(const ldit_cfg *cfg, const void *packed, const void *const *images, const int32_t *heights,
+                            const int32_t *widths, int32_t half_in, float mean, float std, int32_t batch, void *const *tap_out,
+                            void *workspace, size_t workspace_bytes, ldit_stream stream);
+
 /* Same, but brackets every kernel launch with HIP events on `stream`, synchronises, and ADDS the elapsed
  * milliseconds / launch counts per kernel family into ms[LDIT_K_COUNT] / launches[LDIT_K_COUNT].
  * Measurement aid for bench.py's roofline block; not for production use (it blocks the host). */
@@ -244,6 +254,16 @@ int ldit_linear_planes(const void *Xp, int64_t lda, const void *Wp, const void *
  * fp32, written to token rows 1.. of out fp32 [B, 1+P, C]; row 0 = cls + pos[0].  (in_ch*p*p) % 64 == 0, C % 4 == 0. */
 int ldit_embed_bf16(const void *x, const void *patch_w_bf16, const void *patch_b, const void *cls, const void *pos, void *out,
                     void *scratch, int64_t B, int64_t in_ch, int64_t img_h, int64_t img_w, int64_t p, int64_t C, ldit_stream stream);
+
+/* The same embedding fed by the detector's ragged image list instead of the resized batch (the input transform
+ * of ref src/layoutdit/modeling/model.py:50-54 fused into the patch-embed load): `images` / `heights` / `widths` as for
+ * ldit_preprocess_f32 (half_in != 0: fp16 images), img_h x img_w = the transform's fixed_size.  The pass that builds the bf16
+ * im2col matrix evaluates (bilinear(img) - mean) / std itself - the statement of ldit_preprocess_f32, bit for bit - so the
+ * result EQUALS ldit_preprocess_* followed by ldit_embed_bf16, without the fp32 batch in between (one launch and a write + read
+ * of B * in_ch * img_h * img_w * 4 bytes less). */
+int ldit_embed_bf16_images(const void *const *images, const int32_t *heights, const int32_t *widths, int32_t half_in, float mean,
+                           float std, const void *patch_w_bf16, const void *patch_b, const void *cls, const void *pos, void *out,
+                           void *scratch, int64_t B, int64_t in_ch, int64_t img_h, int64_t img_w, int64_t p, int64_t C, ldit_stream stream);
 
 /* ---- fp8 (OCP e4m3) building blocks of the fp8 build (BASELINE.json configs[4]) -----------------------------------------
  * Symmetric scaling: activations per tensor (T ~= scale_T * q, scale_T = amax(T) / 448), weights per output channel

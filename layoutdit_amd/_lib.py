@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libldit_hip.so")
 
-LDIT_ABI_VERSION = 4
+LDIT_ABI_VERSION = 5
 LDIT_MAX_TAPS = 8
 DTYPE_F32, DTYPE_BF16, DTYPE_FP8, DTYPE_F32X3, DTYPE_F32X6 = 0, 1, 3, 4, 5
 FP8_A_COUNT = 4
@@ -51,6 +51,8 @@ SIGNATURES = {
     "ldit_pack_weights": (C.c_int, [C.POINTER(LditCfg), C.POINTER(LditWeights), _vp, _sz, _vp]),
     "ldit_workspace_bytes": (_sz, [C.POINTER(LditCfg), _i32]),
     "ldit_vit_forward": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _i32, C.POINTER(_vp), _vp, _sz, _vp]),
+    "ldit_vit_forward_images": (C.c_int, [C.POINTER(LditCfg), _vp, C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i32), _i32, _f32, _f32, _i32,
+                                          C.POINTER(_vp), _vp, _sz, _vp]),
     "ldit_vit_forward_timed": (C.c_int, [C.POINTER(LditCfg), _vp, _vp, _i32, C.POINTER(_vp), _vp, _sz, _vp,
                                          C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ldit_linear_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
@@ -62,6 +64,8 @@ SIGNATURES = {
     "ldit_layernorm_f32_planes": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, C.c_float, _i32, _vp]),
     "ldit_linear_planes": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _vp]),
     "ldit_embed_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "ldit_embed_bf16_images": (C.c_int, [C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i32), _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                         _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
     "ldit_tap_to_map_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ldit_tap_to_map_bwd_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ldit_linear_bf16": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),

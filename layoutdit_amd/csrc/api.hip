@@ -91,14 +91,25 @@ int linear(const float *X, int lda, const float *W, const float *bias, float *Y,
     return LDIT_OK;
 }
 
+// the pixels as the detector holds them before its input transform: a ragged list of [in_ch, h_i, w_i] images in [0, 1]
+// (ldit_vit_forward_images: the transform is evaluated by the kernel that produces the patch-embedding operand)
+struct ImgSrc {
+    const void *const *images;
+    const int32_t *heights, *widths;
+    bool half_in;
+    float mean, std;
+};
+
 int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batch, void *const *tap_out, void *workspace,
-            size_t ws_bytes, hipStream_t stream, Probe &probe)
+            size_t ws_bytes, hipStream_t stream, Probe &probe, const ImgSrc *imgs = nullptr)
 {
     Geo g;
     LDIT_TRY(geometry(cfg, g));
     if (batch <= 0) return fail(LDIT_EINVAL, "batch %d must be positive", batch);
-    if (!packed || !x || !workspace) return fail(LDIT_EINVAL, "null packed / x / workspace pointer");
-    if (!aligned16(packed) || !aligned16(x) || !aligned16(workspace)) return fail(LDIT_EINVAL, "pointers must be 16-byte aligned");
+    if (!packed || (!x && !imgs) || !workspace) return fail(LDIT_EINVAL, "null packed / x / workspace pointer");
+    if (!aligned16(packed) || (x && !aligned16(x)) || !aligned16(workspace)) return fail(LDIT_EINVAL, "pointers must be 16-byte aligned");
+    if (imgs && (!imgs->images || !imgs->heights || !imgs->widths || !(imgs->std > 0.0f) || batch > 65535))
+        return fail(LDIT_EINVAL, "image list: null array, non-positive std or more than 65535 images");
     if (cfg->n_taps && !tap_out) return fail(LDIT_EINVAL, "tap_out is null");
     for (int i = 0; i < cfg->n_taps; ++i)
         if (!tap_out[i] || !aligned16(tap_out[i])) return fail(LDIT_EINVAL, "tap_out[%d] is null or misaligned", i);
@@ -137,8 +148,12 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
         // (split-fp32 builds: the im2col rows hold the bf16 planes of the pixels, the GEMM walks the plane products)
         const int Se = split_planes_of(cfg->dtype) ? split_planes_of(cfg->dtype) : 1;
         char *patches = ws + wm.big;
-        LDIT_RUN(probe, LDIT_K_OTHER, launch_patches_rows(static_cast<const float *>(x), patches, batch, g.in_ch, cfg->img_h, cfg->img_w,
-                                                         g.p, stream, Se));
+        if (imgs)       // normalise + bilinear resize of the ragged list INSIDE this pass - no fp32 batch in between
+            LDIT_RUN(probe, LDIT_K_OTHER, launch_patches_rows_images(imgs->images, imgs->half_in, imgs->heights, imgs->widths, batch, g.in_ch,
+                                                                    imgs->mean, imgs->std, cfg->img_h, cfg->img_w, g.p, patches, stream, Se));
+        else
+            LDIT_RUN(probe, LDIT_K_OTHER, launch_patches_rows(static_cast<const float *>(x), patches, batch, g.in_ch, cfg->img_h, cfg->img_w,
+                                                             g.p, stream, Se));
         GemmExtra xe{};
         xe.pos = F32(pm.pos); xe.patches = g.P;
         if (Se == 2) { xe.nseg = 3; xe.seg_a = 0x001u; xe.seg_w = 0x010u; }
@@ -148,8 +163,17 @@ int forward(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batc
                                                         EPI_EMBED, nullptr, nullptr, nullptr, xe, stream));
         LDIT_RUN(probe, LDIT_K_OTHER, launch_cls_rows(F32(pm.cls), F32(pm.pos), h, batch, g.T, C, stream));
     } else {
-        LDIT_TRY(embed(g, static_cast<const float *>(x), F32(pm.patch_w), F32(pm.patch_b), F32(pm.cls), F32(pm.pos), h, batch,
-                       cfg->img_h, cfg->img_w, stream, probe));
+        const float *xp = static_cast<const float *>(x);
+        if (imgs) {
+            // the fp32 GEMM gathers the NCHW pixels on its LDS-DMA operand path, where nothing can be blended: the batch is produced
+            // first (same statement, image_blend.h), into `big` - free until layer 0
+            const size_t pix = (size_t)batch * g.in_ch * cfg->img_h * cfg->img_w * 4;
+            if (wm.total - wm.big < pix) return fail(LDIT_EUNSUPPORTED, "image list: the pixel batch does not fit the workspace of this geometry");
+            LDIT_RUN(probe, LDIT_K_OTHER, launch_preprocess(imgs->images, imgs->half_in, imgs->heights, imgs->widths, batch, g.in_ch, imgs->mean,
+                                                           imgs->std, cfg->img_h, cfg->img_w, big, stream));
+            xp = big;
+        }
+        LDIT_TRY(embed(g, xp, F32(pm.patch_w), F32(pm.patch_b), F32(pm.cls), F32(pm.pos), h, batch, cfg->img_h, cfg->img_w, stream, probe));
     }
     if (float *t0 = tap_for(0)) {
         LDIT_HIP_CHECK(hipMemcpyAsync(t0, h, act_bytes, hipMemcpyDeviceToDevice, stream));
@@ -388,6 +412,15 @@ int ldit_vit_forward(const ldit_cfg *cfg, const void *packed, const void *x, int
     return forward(cfg, packed, x, batch, tap_out, workspace, workspace_bytes, static_cast<hipStream_t>(stream), probe);
 }
 
+int ldit_vit_forward_images(const ldit_cfg *cfg, const void *packed, const void *const *images, const int32_t *heights,
+                            const int32_t *widths, int32_t half_in, float mean, float std, int32_t batch, void *const *tap_out,
+                            void *workspace, size_t workspace_bytes, ldit_stream stream)
+{
+    Probe probe;
+    const ImgSrc src{images, heights, widths, half_in != 0, mean, std};
+    return forward(cfg, packed, nullptr, batch, tap_out, workspace, workspace_bytes, static_cast<hipStream_t>(stream), probe, &src);
+}
+
 int ldit_vit_forward_timed(const ldit_cfg *cfg, const void *packed, const void *x, int32_t batch, void *const *tap_out,
                            void *workspace, size_t workspace_bytes, ldit_stream stream, double *ms, int64_t *launches)
 {
@@ -514,6 +547,31 @@ int ldit_embed_bf16(const void *x, const void *patch_w_bf16, const void *patch_b
         return fail(LDIT_EUNSUPPORTED, "embed_bf16: operand exceeds 2^31 elements");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     LDIT_TRY(launch_patches_rows(static_cast<const float *>(x), scratch, (int)B, (int)in_ch, (int)img_h, (int)img_w, (int)p, stream));
+    GemmExtra xe{};
+    xe.pos = static_cast<const float *>(pos); xe.patches = (int)P;
+    LDIT_TRY(launch_gemm_bf16_ex(scratch, (int)Kp, patch_w_bf16, static_cast<const float *>(patch_b), out, (int)C, (int)(B * P), (int)C, (int)Kp,
+                                 EPI_EMBED, nullptr, nullptr, nullptr, xe, stream));
+    return launch_cls_rows(static_cast<const float *>(cls), static_cast<const float *>(pos), static_cast<float *>(out), (int)B, (int)(P + 1),
+                           (int)C, stream);
+}
+
+int ldit_embed_bf16_images(const void *const *images, const int32_t *heights, const int32_t *widths, int32_t half_in, float mean,
+                           float std, const void *patch_w_bf16, const void *patch_b, const void *cls, const void *pos, void *out,
+                           void *scratch, int64_t B, int64_t in_ch, int64_t img_h, int64_t img_w, int64_t p, int64_t C, ldit_stream stream_)
+{
+    if (B <= 0 || B > 65535 || in_ch <= 0 || img_h <= 0 || img_w <= 0 || p <= 0 || C <= 0) return fail(LDIT_EINVAL, "embed_bf16_images: empty problem");
+    if (img_h % p || img_w % p) return fail(LDIT_EINVAL, "embed_bf16_images: target %lldx%lld is not a multiple of patch %lld", (long long)img_h, (long long)img_w, (long long)p);
+    if (!images || !heights || !widths || !patch_w_bf16 || !patch_b || !cls || !pos || !out || !scratch) return fail(LDIT_EINVAL, "embed_bf16_images: null operand");
+    if (!(std > 0.0f)) return fail(LDIT_EINVAL, "embed_bf16_images: std must be positive");
+    if (!aligned16(out) || !aligned16(pos) || !aligned16(scratch) || !aligned16(patch_w_bf16) || (C & 3))
+        return fail(LDIT_EINVAL, "embed_bf16_images: out / pos / scratch / patch_w must be 16-byte aligned, C a multiple of 4");
+    const int64_t P = (img_h / p) * (img_w / p), Kp = in_ch * p * p;
+    if (Kp % 64) return fail(LDIT_EUNSUPPORTED, "embed_bf16_images: in_ch*p*p = %lld must be a multiple of 64", (long long)Kp);
+    if (B * in_ch * img_h * img_w >= (1ll << 31) || B * (P + 1) * C >= (1ll << 31) || B * P * Kp >= (1ll << 31))
+        return fail(LDIT_EUNSUPPORTED, "embed_bf16_images: operand exceeds 2^31 elements");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    LDIT_TRY(launch_patches_rows_images(images, half_in != 0, heights, widths, (int)B, (int)in_ch, mean, std, (int)img_h, (int)img_w, (int)p,
+                                        scratch, stream));
     GemmExtra xe{};
     xe.pos = static_cast<const float *>(pos); xe.patches = (int)P;
     LDIT_TRY(launch_gemm_bf16_ex(scratch, (int)Kp, patch_w_bf16, static_cast<const float *>(patch_b), out, (int)C, (int)(B * P), (int)C, (int)Kp,

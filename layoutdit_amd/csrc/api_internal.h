@@ -111,6 +111,9 @@ inline Workspace workspace_map(const Geo &g, int batch, int dtype)
     w.y = take(M * g.C * act);     // LayerNorm output, then attention output
     size_t big = M * wide * act;   // fused q|k|v, later the MLP hidden (never live together)
     if (dtype != LDIT_F32 && big < (size_t)batch * g.P * g.Kp * 2) big = (size_t)batch * g.P * g.Kp * 2;   // before layer 0: bf16 im2col of the batch
+    // fp32 build fed by an image list (ldit_vit_forward_images): the transformed fp32 batch lives here until the embedding has read it
+    // (only geometries narrower than 768 columns per token need the extra room)
+    if (dtype == LDIT_F32 && big < (size_t)batch * g.P * g.Kp * 4) big = (size_t)batch * g.P * g.Kp * 4;
     w.big = take(big);
     w.total = o;
     return w;

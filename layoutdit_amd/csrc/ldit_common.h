@@ -212,6 +212,11 @@ int launch_tap_to_map(const float *tap, float *out, int B, int Gh, int Gw, int C
 int launch_tap_to_map_bwd(const float *dmap, float *dtap, int B, int Gh, int Gw, int C, float scale, hipStream_t stream);
 int launch_preprocess(const void *const *images, bool half_in, const int *heights, const int *widths, int B, int in_ch, float mean,
                       float std, int out_h, int out_w, float *out, hipStream_t stream);
+struct ImageList;
+int fill_image_list(ImageList &l, const void *const *images, const int *heights, const int *widths, int B, int first, float mean, float std);
+// the bf16 (or plane) im2col rows of the patch embedding straight from a ragged image list: the input transform fused into the load
+int launch_patches_rows_images(const void *const *images, bool half_in, const int *heights, const int *widths, int B, int in_ch,
+                               float mean, float std, int out_h, int out_w, int p, void *out, hipStream_t stream, int planes = 1);
 int launch_cast_f16(const void *src, void *dst, size_t n, bool widen, hipStream_t stream);
 int launch_fpn_merge(const float *lat, const float *top, float *out, int B, int Gh, int Gw, int Ch, float scale, int top_h,
                      int top_w, hipStream_t stream);

@@ -1,6 +1,7 @@
 // Small HBM-bound kernels around the GEMMs: CLS rows of the embedding, the fused q/k/v bias, and DiTBackbone's tap
 // post-processing (CLS drop + [C,Gh,Gw] view + bilinear rescale, ref src/layoutdit/modeling/dit_backbone.py:50-61).
 #include "ldit_common.h"
+#include "image_blend.h"
 
 namespace ldit {
 
@@ -108,14 +109,12 @@ __global__ void __launch_bounds__(256) tap_to_map_tiled(const float *__restrict_
 // Input transform: up to PRE_MAX images per launch, descriptors in the kernel arguments (no device-side table).
 // One thread per 4 consecutive output pixels of one (image, channel, row): reads are two input rows (L2-friendly),
 // writes are 16 B per lane, contiguous across the wave.  normalise-then-resize == resize-then-normalise for a
-// per-channel affine map, so the normalisation is applied to the interpolated value.
-constexpr int PRE_MAX = 48;
+// per-channel affine map, so the normalisation is applied to the interpolated value (image_blend.h: the one statement every
+// producer of these pixels shares).
 struct PreArgs {
-    const void *img[PRE_MAX];
-    int h[PRE_MAX], w[PRE_MAX];
+    ImageList l;
     float *out;
-    int n, in_ch, out_h, out_w, first;
-    float mean, inv_std;
+    int in_ch, out_h, out_w;
 };
 
 // IN = float or _Float16 (the reference's trainer hands fp16 images to the detector, ref trainer.py:153-155); arithmetic and
@@ -129,24 +128,15 @@ __global__ void __launch_bounds__(256) preprocess_images(const PreArgs a)
     const int i = blockIdx.y;
     if (idx >= per_img) return;
     const int ch = idx / (a.out_h * owv), rem = idx - ch * (a.out_h * owv), oy = rem / owv, ox0 = (rem - oy * owv) * 4;
-    const int h = a.h[i], w = a.w[i];
-    const IN *src = static_cast<const IN *>(a.img[i]) + (size_t)ch * h * w;
-    const float sch = (float)h / (float)a.out_h, scw = (float)w / (float)a.out_w;   // F.interpolate(size=...) scale
-    float sy = ((float)oy + 0.5f) * sch - 0.5f; sy = sy < 0.f ? 0.f : sy;
-    int y0 = (int)sy; y0 = y0 > h - 1 ? h - 1 : y0;
-    const int y1 = y0 + (y0 < h - 1);
-    const float ly = sy - (float)y0, hy = 1.f - ly;
-    const IN *r0 = src + (size_t)y0 * w, *r1 = src + (size_t)y1 * w;
-    float *dst = a.out + (((size_t)(a.first + i) * a.in_ch + ch) * a.out_h + oy) * a.out_w + ox0;
+    const int h = a.l.h[i], w = a.l.w[i];
+    const IN *src = static_cast<const IN *>(a.l.img[i]) + (size_t)ch * h * w;
+    const BlendRow br = blend_row(oy, h, a.out_h);
+    const IN *r0 = src + (size_t)br.y0 * w, *r1 = src + (size_t)br.y1 * w;
+    float *dst = a.out + (((size_t)(a.l.first + i) * a.in_ch + ch) * a.out_h + oy) * a.out_w + ox0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         if (ox0 + e >= a.out_w) break;
-        float sx = ((float)(ox0 + e) + 0.5f) * scw - 0.5f; sx = sx < 0.f ? 0.f : sx;
-        int x0 = (int)sx; x0 = x0 > w - 1 ? w - 1 : x0;
-        const int x1 = x0 + (x0 < w - 1);
-        const float lx = sx - (float)x0, hx = 1.f - lx;
-        const float v = hy * (hx * (float)r0[x0] + lx * (float)r0[x1]) + ly * (hx * (float)r1[x0] + lx * (float)r1[x1]);
-        dst[e] = (v - a.mean) * a.inv_std;
+        dst[e] = blend_pixel(r0, r1, ox0 + e, w, a.out_w, br, a.l.mean, a.l.inv_std);
     }
 }
 
@@ -208,21 +198,28 @@ int launch_cast_f16(const void *src, void *dst, size_t n, bool widen, hipStream_
     return LDIT_OK;
 }
 
+int fill_image_list(ImageList &l, const void *const *images, const int *heights, const int *widths, int B, int first, float mean, float std)
+{
+    l.n = (B - first) < PRE_MAX ? (B - first) : PRE_MAX;
+    for (int i = 0; i < l.n; ++i) {
+        if (!images[first + i] || heights[first + i] <= 0 || widths[first + i] <= 0)
+            return fail(LDIT_EINVAL, "image %d is null or empty", first + i);
+        l.img[i] = images[first + i]; l.h[i] = heights[first + i]; l.w[i] = widths[first + i];
+    }
+    l.first = first; l.mean = mean; l.inv_std = 1.0f / std;
+    return LDIT_OK;
+}
+
 int launch_preprocess(const void *const *images, bool half_in, const int *heights, const int *widths, int B, int in_ch, float mean,
                       float std, int out_h, int out_w, float *out, hipStream_t stream)
 {
     for (int first = 0; first < B; first += PRE_MAX) {
         PreArgs a{};
-        a.n = (B - first) < PRE_MAX ? (B - first) : PRE_MAX;
-        for (int i = 0; i < a.n; ++i) {
-            if (!images[first + i] || heights[first + i] <= 0 || widths[first + i] <= 0)
-                return fail(LDIT_EINVAL, "preprocess: image %d is null or empty", first + i);
-            a.img[i] = images[first + i]; a.h[i] = heights[first + i]; a.w[i] = widths[first + i];
-        }
-        a.out = out; a.in_ch = in_ch; a.out_h = out_h; a.out_w = out_w; a.first = first; a.mean = mean; a.inv_std = 1.0f / std;
+        if (int rc = fill_image_list(a.l, images, heights, widths, B, first, mean, std)) return rc;
+        a.out = out; a.in_ch = in_ch; a.out_h = out_h; a.out_w = out_w;
         const int per_img = in_ch * out_h * ((out_w + 3) / 4);
-        if (half_in) hipLaunchKernelGGL(preprocess_images<_Float16>, dim3((per_img + 255) / 256, a.n), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL(preprocess_images<float>, dim3((per_img + 255) / 256, a.n), dim3(256), 0, stream, a);
+        if (half_in) hipLaunchKernelGGL(preprocess_images<_Float16>, dim3((per_img + 255) / 256, a.l.n), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(preprocess_images<float>, dim3((per_img + 255) / 256, a.l.n), dim3(256), 0, stream, a);
         LDIT_HIP_CHECK(hipGetLastError());
     }
     return LDIT_OK;

@@ -6,6 +6,7 @@
 // every workgroup writes the partial sums of its rows to part[block][column], `reduce_jobs` then adds the partials of up
 // to 16 vectors in one launch, in a fixed order - gradients are bit-reproducible run to run.
 #include "ldit_common.h"
+#include "image_blend.h"
 
 namespace ldit {
 
@@ -465,6 +466,36 @@ __global__ void __launch_bounds__(256) patches_rows(const float *__restrict__ x,
     }
 }
 
+// The same im2col rows straight from the detector's RAGGED image list ("input transform fused into the patch-embed
+// load"): every value is the normalised, bilinearly resized pixel of image_blend.h - the statement ldit_preprocess_f32/_f16 evaluates,
+// hence its bits - rounded to bf16 (or split into planes) on the spot.  The fp32 out_h x out_w batch is never written or read back
+// (38.5 MB each way at ViT-B bs=64) and one launch disappears.  One workgroup per (image, patch row, channel) as above.
+struct PatchImgArgs {
+    ImageList l;
+    bf16_t *out;
+    int in_ch, out_h, out_w, p, gw, gh, Kp, planes;
+};
+
+template <typename IN>
+__global__ void __launch_bounds__(256) patches_rows_images(const PatchImgArgs a)
+{
+    const int ch = blockIdx.x % a.in_ch, gy = (blockIdx.x / a.in_ch) % a.gh, i = blockIdx.x / (a.in_ch * a.gh);
+    const int h = a.l.h[i], w = a.l.w[i], b = a.l.first + i;
+    const IN *src = static_cast<const IN *>(a.l.img[i]) + (size_t)ch * h * w;
+    for (int t = threadIdx.x; t < a.p * a.out_w; t += 256) {
+        const int dy = t / a.out_w, xx = t - dy * a.out_w, gx = xx / a.p, dx = xx - gx * a.p;
+        const BlendRow br = blend_row(gy * a.p + dy, h, a.out_h);
+        float v = blend_pixel(src + (size_t)br.y0 * w, src + (size_t)br.y1 * w, xx, w, a.out_w, br, a.l.mean, a.l.inv_std);
+        const size_t m = ((size_t)b * a.gh + gy) * a.gw + gx;
+        bf16_t *d = a.out + m * ((size_t)a.planes * a.Kp) + (ch * a.p + dy) * a.p + dx;
+        for (int sp = 0; sp < a.planes; ++sp) {
+            const bf16_t q = (bf16_t)v;
+            d[(size_t)sp * a.Kp] = q;
+            v -= (float)q;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) zero_pad_columns(bf16_t *__restrict__ buf, int rows, int M, int Mp)
 {
     const int r = blockIdx.x, pad = Mp - M;
@@ -630,6 +661,21 @@ int launch_patches_rows(const float *x, void *out, int B, int in_ch, int img_h, 
     const int gh = img_h / p, gw = img_w / p;
     LAUNCH_CHECKED(patches_rows, dim3((unsigned)(B * gh * in_ch)), dim3(256), 0, stream, x, static_cast<bf16_t *>(out), in_ch, img_h,
                    img_w, p, gw, gh, in_ch * p * p, planes);
+    return LDIT_OK;
+}
+
+int launch_patches_rows_images(const void *const *images, bool half_in, const int *heights, const int *widths, int B, int in_ch,
+                               float mean, float std, int out_h, int out_w, int p, void *out, hipStream_t stream, int planes)
+{
+    const int gh = out_h / p, gw = out_w / p;
+    for (int first = 0; first < B; first += PRE_MAX) {
+        PatchImgArgs a{};
+        if (int rc = fill_image_list(a.l, images, heights, widths, B, first, mean, std)) return rc;
+        a.out = static_cast<bf16_t *>(out); a.in_ch = in_ch; a.out_h = out_h; a.out_w = out_w; a.p = p; a.gw = gw; a.gh = gh;
+        a.Kp = in_ch * p * p; a.planes = planes;
+        if (half_in) LAUNCH_CHECKED(patches_rows_images<_Float16>, dim3((unsigned)(a.l.n * gh * in_ch)), dim3(256), 0, stream, a);
+        else LAUNCH_CHECKED(patches_rows_images<float>, dim3((unsigned)(a.l.n * gh * in_ch)), dim3(256), 0, stream, a);
+    }
     return LDIT_OK;
 }
 

@@ -126,6 +126,20 @@ def sum_over_ranks(r: Rank, value: float) -> float:
     return float(t.item())
 
 
+def gather_over_ranks(r: Rank, values) -> list:
+    """Every rank contributes the same number of floats; every rank gets ``[world][len(values)]`` back (control plane only:
+    the per-rank throughput and MFMA utilisation that ``bench.py --gpus N`` reports - a slow rank must be visible, not hidden
+    behind the max-over-ranks time)."""
+    vals = [float(v) for v in values]
+    if r.world == 1 and not dist.is_initialized():
+        return [vals]
+    dev = torch.device("cuda", r.local_rank) if r.backend == "nccl" else torch.device("cpu")
+    mine = torch.tensor(vals, dtype=torch.float64, device=dev)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [t.cpu().tolist() for t in out]
+
+
 def finalize(r: Rank) -> None:
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -72,6 +72,14 @@ class DetectorInputTransform(nn.Module):
                 out_targets.append(t)
         return ImageList(batch, [(self.out_h, self.out_w)] * len(images)), out_targets
 
+    def encode(self, encoder, images: List[torch.Tensor], taps: Optional[Sequence[int]] = None):
+        """``encoder(self(images)[0].tensors)`` in eval mode with the transform FUSED into the encoder's patch-embedding load
+        (``DiTEncoder.forward_image_list`` -> ``ldit_vit_forward_images``): same taps bit for bit, and the bf16 /
+        fp8 / split-fp32 builds skip the fp32 ``[B, 3, H, W]`` batch altogether.  For callers that own the loop; torchvision's
+        ``GeneralizedRCNN.forward`` hands the backbone the already transformed batch, which stays the two-step path."""
+        return encoder.forward_image_list([img.contiguous() for img in images], size=(self.out_h, self.out_w), mean=self.mean,
+                                          std=self.std, taps=taps)
+
     def postprocess(self, result: List[Dict[str, torch.Tensor]], image_shapes: List[Tuple[int, int]],
                     original_image_sizes: List[Tuple[int, int]]) -> List[Dict[str, torch.Tensor]]:
         """Detections back in the coordinates of the original images (what the evaluator reads, ref evaluator.py:237-258)."""

@@ -427,6 +427,46 @@ class DiTEncoder(nn.Module):
         hidden = self._like_input(hidden, pixel_values.dtype)
         return DiTEncoderOutput(hidden_states=tuple(hidden), last_hidden_state=hidden[cfg.num_hidden_layers])
 
+    def forward_image_list(self, images: Sequence[torch.Tensor], size: Optional[Tuple[int, int]] = None, mean: float = 0.5,
+                           std: float = 0.5, taps: Optional[Sequence[int]] = None) -> DiTEncoderOutput:
+        """Inference forward fed by the detector's image list BEFORE its input transform (ref model.py:50-54: torchvision's
+        ``GeneralizedRCNNTransform`` with ``fixed_size``, ``image_mean = image_std = 0.5``): a ragged list of ``[3, h, w]`` tensors in
+        [0, 1], fp32 or fp16.  Equal - bit for bit - to ``self(DetectorInputTransform(...)(images).tensors)``, but the bf16 / fp8 /
+        split-fp32 builds never materialise the resized fp32 batch: the pass that writes the patch-embedding operand evaluates the
+        normalise + bilinear resize itself (C ABI ``ldit_vit_forward_images``).  Eval mode only (the training
+        forward keeps the two-step path: its backward re-reads the resized pixels)."""
+        from .. import ops
+        cfg = self.config
+        if self.training:
+            raise RuntimeError("forward_image_list is the inference entry; in train mode feed DetectorInputTransform's batch to forward()")
+        H, W = size or (cfg.image_size, cfg.image_size)
+        p = cfg.patch_size
+        if H % p or W % p:
+            raise ValueError(f"target size {H}x{W} is not a multiple of the patch size {p}")
+        imgs, ptrs, hs, ws_, half, ch = ops.image_list_args(images)
+        if ch != cfg.num_channels:
+            raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the "
+                             f"configuration. Expected {cfg.num_channels} but got {ch}.")
+        taps = list(cfg.taps if taps is None else taps)
+        device = imgs[0].device
+        B = len(imgs)
+        with torch.no_grad(), torch.cuda.device(device):
+            lib = _lib.load()
+            gh, gw = H // p, W // p
+            lcfg = self._lcfg(H, W, taps)
+            packed = self._pack(lcfg, self._position_table(gh, gw), device)
+            ws = self._scratch(lcfg, B, device)
+            T = gh * gw + 1
+            outs = [torch.empty((B, T, cfg.hidden_size), dtype=torch.float32, device=device) for _ in taps]
+            tap_ptrs = (C.c_void_p * max(len(outs), 1))(*[o.data_ptr() for o in outs])
+            _lib.check(lib.ldit_vit_forward_images(C.byref(lcfg), packed.data_ptr(), ptrs, hs, ws_, int(half), float(mean), float(std), B,
+                                                   tap_ptrs, ws.data_ptr(), ws.numel(), torch.cuda.current_stream(device).cuda_stream))
+        hidden: List[Optional[torch.Tensor]] = [None] * (cfg.num_hidden_layers + 1)
+        for t, o in zip(taps, outs):
+            hidden[t] = o
+        hidden = self._like_input(hidden, torch.float16 if half else torch.float32)
+        return DiTEncoderOutput(hidden_states=tuple(hidden), last_hidden_state=hidden[cfg.num_hidden_layers])
+
     @staticmethod
     def _pixels_f32(pixel_values: torch.Tensor) -> torch.Tensor:
         """fp32 NCHW contiguous pixels for the kernels.  fp16 batches (the reference's trainer feeds ``.half()`` images under

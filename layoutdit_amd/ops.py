@@ -188,23 +188,51 @@ def preprocess(images: Sequence[torch.Tensor], size=224, mean: float = 0.5, std:
     mean = std = 0.5): list of ``[3, h, w]`` images in [0, 1] (all fp32 or all fp16) -> normalised, bilinearly resized
     fp32 ``[B, 3, size, size]``."""
     lib = _lib.load()
-    if len(images) == 0:
-        raise ValueError("preprocess: empty image list")
-    half = images[0].dtype == torch.float16
-    imgs = [(_req16 if half else _req)(t, f"images[{i}]") for i, t in enumerate(images)]
-    ch = imgs[0].shape[0]
-    if any(t.dim() != 3 or t.shape[0] != ch for t in imgs):
-        raise ValueError("preprocess: every image must be [C, h, w] with the same C")
+    imgs, ptrs, hs, ws, half, ch = image_list_args(images)
     B = len(imgs)
     out_h, out_w = (size, size) if isinstance(size, int) else (int(size[0]), int(size[1]))
     out = torch.empty((B, ch, out_h, out_w), device=imgs[0].device, dtype=torch.float32)
-    ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in imgs])
-    hs = (C.c_int32 * B)(*[t.shape[1] for t in imgs])
-    ws = (C.c_int32 * B)(*[t.shape[2] for t in imgs])
     if half:
         _launch(_device(*imgs), lib.ldit_preprocess_f16, ptrs, hs, ws, B, ch, mean, std, out_h, out_w, _ptr(out))
     else:
         _launch(_device(*imgs), lib.ldit_preprocess_f32, ptrs, hs, ws, B, ch, mean, std, out_h, out_w, _ptr(out))
+    return out
+
+
+def image_list_args(images: Sequence[torch.Tensor]):
+    """``(checked tensors, device pointers, heights, widths, half_in, channels)`` of a ragged list of ``[C, h, w]`` images (all fp32
+    or all fp16, same C, one GPU) - the HOST arrays the image-list entries of the C ABI take."""
+    if len(images) == 0:
+        raise ValueError("empty image list")
+    half = images[0].dtype == torch.float16
+    imgs = [(_req16 if half else _req)(t, f"images[{i}]") for i, t in enumerate(images)]
+    ch = imgs[0].shape[0]
+    if any(t.dim() != 3 or t.shape[0] != ch for t in imgs):
+        raise ValueError("every image must be [C, h, w] with the same C")
+    B = len(imgs)
+    ptrs = (C.c_void_p * B)(*[t.data_ptr() for t in imgs])
+    hs = (C.c_int32 * B)(*[t.shape[1] for t in imgs])
+    ws = (C.c_int32 * B)(*[t.shape[2] for t in imgs])
+    return imgs, ptrs, hs, ws, half, ch
+
+
+def embed_bf16_images(images: Sequence[torch.Tensor], patch_w_bf16: torch.Tensor, patch_b: torch.Tensor, cls: torch.Tensor,
+                      pos: torch.Tensor, patch: int, size=224, mean: float = 0.5, std: float = 0.5) -> torch.Tensor:
+    """``embed_bf16(preprocess(images, size, mean, std), ...)`` with the input transform evaluated inside the im2col pass (SURVEY.md
+    8(f)-2; ref model.py:50-54): same bits, no fp32 batch in between."""
+    lib = _lib.load()
+    imgs, ptrs, hs, ws, half, ch = image_list_args(images)
+    patch_b, cls, pos = _req(patch_b, "patch_b"), _req(cls, "cls"), _req(pos, "pos")
+    if patch_w_bf16.dtype != torch.bfloat16 or not patch_w_bf16.is_contiguous():
+        raise ValueError("patch_w_bf16 must be a contiguous bfloat16 tensor")
+    out_h, out_w = (size, size) if isinstance(size, int) else (int(size[0]), int(size[1]))
+    B, Cc = len(imgs), patch_w_bf16.shape[0]
+    P = (out_h // patch) * (out_w // patch)
+    dev = imgs[0].device
+    out = torch.empty((B, P + 1, Cc), device=dev, dtype=torch.float32)
+    scratch = torch.empty((B * P, ch * patch * patch), device=dev, dtype=torch.bfloat16)
+    _launch(_device(*imgs, patch_w_bf16, patch_b, cls, pos), lib.ldit_embed_bf16_images, ptrs, hs, ws, int(half), mean, std,
+            _ptr(patch_w_bf16), _ptr(patch_b), _ptr(cls), _ptr(pos), _ptr(out), _ptr(scratch), B, ch, out_h, out_w, patch, Cc)
     return out
 
 

@@ -224,9 +224,14 @@ class FlatState:
 
     def backward(self, x: torch.Tensor, taps: Sequence[int], dtaps: Sequence[Optional[torch.Tensor]],
                  drop_scales: Optional[torch.Tensor], saved: torch.Tensor, stage_hi: int, stage_lo: int,
-                 timing: Optional[dict] = None) -> None:
+                 timing: Optional[dict] = None, grads: Optional[torch.Tensor] = None) -> None:
+        """``grads``: flat fp32 block the gradients are written to (default: this state's own block, which the next backward
+        overwrites; the autograd path hands in a fresh block per backward so that what it returns stays valid)."""
         lib = _lib.load()
         B = x.shape[0]
+        grads = self.grads if grads is None else grads
+        if grads.numel() != self.numel or grads.dtype != torch.float32 or grads.device != self.device or not grads.is_contiguous():
+            raise ValueError("grads: expected a contiguous fp32 block of the flat parameter layout on the state's device")
         lcfg = self._cfg_with_taps(taps)
         ptrs = (C.c_void_p * max(len(taps), 1))(*[None if d is None else d.data_ptr() for d in dtaps])
         ws = self.workspace(B)
@@ -234,7 +239,7 @@ class FlatState:
         with torch.cuda.device(self.device):
             _lib.check(lib.ldit_vit_backward(C.byref(lcfg), self.params.data_ptr(), self.packed.data_ptr(), x.data_ptr(), B, ptrs,
                                              None if drop_scales is None else drop_scales.data_ptr(), saved.data_ptr(),
-                                             saved.numel(), self.grads.data_ptr(), self.grads.numel() * 4, ws.data_ptr(),
+                                             saved.numel(), grads.data_ptr(), grads.numel() * 4, ws.data_ptr(),
                                              ws.numel(), stage_hi, stage_lo,
                                              torch.cuda.current_stream(self.device).cuda_stream, ms, cnt))
         self._collect(timing, ms, cnt)
@@ -292,15 +297,17 @@ class _EncoderFn(torch.autograd.Function):
         d = [None if g is None else g.contiguous().to(torch.float32) for g in dtaps]
         L = st.lcfg.layers
         (x,) = ctx.saved_tensors
-        st.backward(x, ctx.taps, d, ctx.drop, ctx.saved_acts, L, 0)
-        ctx.saved_acts = None
         need = ctx.needs_input_grad[4:]
         n_extra = 0 if st.native else 1
-        if not any(need):
+        # The per-parameter gradients handed to autograd are views of ONE flat block that this backward owns: the library writes
+        # it directly (every named slot is written by stages L..0), so nothing is copied.  It must not be the state's own block -
+        # AccumulateGrad may keep the views as p.grad, and the next backward would overwrite them (rounds 2-3 cloned 343 MB here).
+        flat = torch.empty_like(st.grads) if any(need) else None
+        st.backward(x, ctx.taps, d, ctx.drop, ctx.saved_acts, L, 0, grads=flat)
+        ctx.saved_acts = None
+        if flat is None:
             return (None,) * (4 + len(st.named) + n_extra)
-        # ONE copy of the flat gradient block (the library overwrites it on the next backward); the per-parameter gradients
-        # handed to autograd are views of that copy
-        flat = st.grads.clone()
+        st.grads = flat             # "the gradients of the last backward" stays where TrainStep and the tests look for it
         grads = tuple(flat[off: off + _numel(shape)].view(shape) if n else None
                       for (_, _, off, shape), n in zip(st.named, need))
         if not st.native:           # the position parameter rides behind the named ones: gradient through the resample's adjoint

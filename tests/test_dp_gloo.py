@@ -82,12 +82,19 @@ def test_bench_launches_itself_at_n_greater_than_one():
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
+    per = rec.pop("per_rank")
     assert rec == {"dryrun": True, "n_gpus": 2, "max_over_ranks": 2.0, "gpus_arg": 2}
+    # BASELINE metric "MFMA util % at 1/2/4/8 GPU": every rank's own throughput and GEMM roofline fraction reach rank 0's line
+    assert per["ranks"] == 2
+    assert per["images_per_sec"] == {"min": 100.0, "mean": 150.0, "max": 200.0, "per_rank": [100.0, 200.0]}
+    assert per["gemm_mfma_roofline_frac"] == {"min": 0.1, "mean": 0.15, "max": 0.2, "per_rank": [0.1, 0.2]}
+    assert per["ms_per_step"]["per_rank"] == [5.0, 6.0]
     # and the torch.distributed.run form keeps working: WORLD_SIZE present -> no self-launch
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], env=env2, capture_output=True,
                          text=True, timeout=300)
-    assert res.returncode == 0 and json.loads(res.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    one = json.loads(res.stdout.strip().splitlines()[-1])
+    assert res.returncode == 0 and one["n_gpus"] == 1 and one["per_rank"]["ranks"] == 1
 
 
 def test_bench_launcher_stops_all_ranks_when_one_dies_in_start_up(tmp_path):

@@ -193,3 +193,102 @@ def test_train_step_bucketed_all_reduce_over_rccl_one_rank():
                HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
     assert res.returncode == 0 and "rccl-train-ok" in res.stdout, res.stderr[-3000:]
+
+
+def _ddp_model(cfgs_mod, synth_mod, torch_mod):
+    from layoutdit_amd.modeling import DiTWithFPN
+    cfg = cfgs_mod.vit_micro()
+    cfg.drop_path_rate = 0.0                    # no coin flips: the two-rank and the one-process gradients are comparable
+    cfg.taps = [1, 1, 2, 3]
+    torch_mod.manual_seed(0)
+    m = DiTWithFPN(config=cfg, compute_dtype="bf16")
+    m.backbone.dit.load_numpy(synth_mod.synth_weights(cfg, 3))
+    g = torch_mod.Generator().manual_seed(7)
+    with torch_mod.no_grad():
+        for p in m.fpn.parameters():
+            if p.dim() == 1:
+                p.copy_(0.05 * torch_mod.randn(p.shape, generator=g))
+    return cfg, m.to("cuda:0").train()
+
+
+def _head_weights(feats, total, lo, hi):
+    """Fixed synthetic upstream gradients standing in for the detection head (RPN / RoI heads are torchvision code, out of
+    scope): one weight tensor per FPN level for the GLOBAL batch, sliced to this rank's images."""
+    ws = {}
+    for i, (k, f) in enumerate(feats.items()):
+        shape = (total,) + tuple(f.shape[1:])
+        n = int(np.prod(shape))
+        ws[k] = torch.from_numpy((synth.normal(90 + i, 9, n) / np.sqrt(n)).astype(np.float32).reshape(shape)[lo:hi].copy()).to(f.device)
+    return ws
+
+
+def _ddp_worker(rank, world, port, total, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    r = dp.init(backend="gloo")
+    try:
+        cfg, m = _ddp_model(cfgs, synth, torch)
+        # the wrapper a maintainer of the reference would use (ref README.md:59 "Add support for distributed training");
+        # find_unused_parameters: BEiT's mask token and pooler LayerNorm never receive a gradient (with HF's BeitModel neither)
+        ddp = DDP(m, device_ids=[0], find_unused_parameters=True)
+        opt = torch.optim.AdamW(ddp.parameters(), lr=1e-4, weight_decay=0.0)          # ref trainer.py:62-68
+        lo, hi = dp.shard_range(total, r.rank, r.world)
+        x = torch.from_numpy(synth.synth_images(hi - lo, 64, 64, seed=5, kind="uniform", first_index=lo)).to("cuda:0")
+        grads = None
+        for it in range(2):                                                           # two iterations: the reducer must re-arm
+            opt.zero_grad()
+            feats = ddp(x)
+            ws = _head_weights(feats, total, lo, hi)
+            loss = sum((f * ws[k]).sum() for k, f in feats.items())                   # ref trainer.py:169-178
+            loss.backward()
+            if it == 0:
+                grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters() if p.grad is not None}
+            opt.step()
+        torch.cuda.synchronize()
+        params = {k: p.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+        q.put((r.rank, grads, params))
+    finally:
+        dp.finalize(r)
+
+
+def test_dit_with_fpn_under_distributed_data_parallel_two_ranks():
+    """North-star: "RCCL all-reduce of the detection-head gradients ... only when training".  DiTWithFPN (FPN parameters + the
+    encoder through the autograd path, its parameters re-homed as views of a flat block at the first training forward) wrapped in
+    torch's DistributedDataParallel, loss.backward() + torch.optim.AdamW as ref trainer.py:62-68,169-180, two ranks on the box's
+    one card (gloo here, RCCL on a real node - same wrapper): FPN AND encoder gradients identical on both ranks and equal to
+    1 / world x the single-process gradient of the concatenated batch; the replicas stay identical after two optimizer steps."""
+    world, total, port = 2, 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=600) for _ in range(world)), key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, p0), (_, g1, p1) = got
+    assert set(g0) == set(g1) and any(k.startswith("fpn.") for k in g0) and any(k.startswith("backbone.dit.encoder") for k in g0)
+    for k in g0:
+        np.testing.assert_array_equal(g0[k], g1[k], err_msg=k)        # DDP's averaged gradient: the same bits on both ranks
+    for k in p0:
+        np.testing.assert_array_equal(p0[k], p1[k], err_msg=k)        # ... hence identical replicas after the optimizer steps
+    assert not any(k.endswith("mask_token") or "pooler" in k for k in g0)
+    # one process, the concatenated batch
+    cfg, m = _ddp_model(cfgs, synth, torch)
+    x = torch.from_numpy(synth.synth_images(total, 64, 64, seed=5, kind="uniform")).to("cuda:0")
+    feats = m(x)
+    ws = _head_weights(feats, total, 0, total)
+    sum((f * ws[k]).sum() for k, f in feats.items()).backward()
+    torch.cuda.synchronize()
+    worst = ("", 0.0)
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            assert k not in g0
+            continue
+        full = p.grad.detach().cpu().numpy().astype(np.float64) / world
+        err = np.linalg.norm(g0[k].astype(np.float64) - full) / max(np.linalg.norm(full), 1e-30)
+        worst = max(worst, (k, err), key=lambda t: t[1])
+        # same arithmetic up to the order of the fp32 sums over the batch and the GEMM tiling the row count selects (bf16 operands)
+        assert err < 5e-3, (k, err)
+    print("DDP two ranks vs one process, worst tensor:", worst)

@@ -288,6 +288,65 @@ def test_detector_input_transform_ragged_list(dtype):
         assert torch.allclose(b1["boxes"].cpu(), b0, atol=1e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_input_transform_fused_into_the_patch_embedding_load(dtype):
+    """SURVEY.md 8(f)-2 / ref model.py:50-54: ldit_embed_bf16_images builds the bf16 patch matrix straight from the ragged [0, 1]
+    image list - normalise + bilinear resize inside the im2col pass.  EQUAL (torch.equal: one shared blend statement,
+    csrc/image_blend.h) to DetectorInputTransform -> ldit_embed_bf16, and within the bf16 embedding's gate of the float64
+    embedding of F.interpolate's pixels."""
+    cfg = cfgs.vit_tiny()
+    w = synth.synth_weights(cfg, 2)
+    sizes = [(300, 200), (224, 224), (97, 411), (640, 480), (31, 17)]
+    imgs = [torch.from_numpy(np.clip(0.5 + 0.3 * _rand(20 + i, 3, h, wd), 0, 1)).to(dtype).to(DEV) for i, (h, wd) in enumerate(sizes)]
+    pw = torch.from_numpy(w["embeddings.patch_embeddings.projection.weight"]).to(DEV)
+    pw16 = ops.cast_bf16(pw.reshape(cfg.hidden_size, -1).contiguous())
+    pb = torch.from_numpy(w["embeddings.patch_embeddings.projection.bias"]).to(DEV)
+    cls = torch.from_numpy(w["embeddings.cls_token"].reshape(-1)).to(DEV)
+    pos = torch.from_numpy(w["embeddings.position_embeddings"].reshape(-1, cfg.hidden_size)).to(DEV)
+    il, _ = DetectorInputTransform()(imgs)
+    two_step = ops.embed_bf16(il.tensors, pw16, pb, cls, pos, 16)
+    fused = ops.embed_bf16_images(imgs, pw16, pb, cls, pos, 16, size=224)
+    assert torch.equal(fused, two_step)
+    # against torch's own resize + a float64 embedding (bf16 operand rounding is all that separates them)
+    ref_px = torch.stack([F.interpolate(((im.float().cpu() - 0.5) / 0.5)[None], size=(224, 224), mode="bilinear", align_corners=False)[0]
+                          for im in imgs]).double()
+    patches = ref_px.reshape(5, 3, 14, 16, 14, 16).permute(0, 2, 4, 1, 3, 5).reshape(5, 196, 768)
+    emb = patches @ pw.cpu().double().reshape(cfg.hidden_size, -1).t() + pb.cpu().double() + pos.cpu().double()[1:]
+    assert rel_l2(fused[:, 1:].cpu().numpy(), emb.numpy()) < 5e-3
+    assert rel_l2(fused[:, 0].cpu().numpy(), (cls + pos[0]).cpu().double().expand(5, -1).numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("build", ["f32", "bf16", "f32x3", "fp8"])
+def test_forward_image_list_equals_transform_then_forward(build):
+    """ldit_vit_forward_images (DiTEncoder.forward_image_list / DetectorInputTransform.encode): the whole forward fed by the ragged
+    list - every build returns the taps of the two-step path bit for bit (the low-precision builds without ever writing the fp32
+    224 x 224 batch; the fp32 build, whose GEMM gathers pixels by LDS-DMA, produces it in its workspace)."""
+    cfg = cfgs.vit_micro() if build != "fp8" else cfgs.vit_micro()
+    size = 64
+    w = synth.synth_weights(cfg, 4)
+    sizes = [(80, 50), (64, 64), (33, 129)]
+    imgs = [torch.from_numpy(np.clip(0.5 + 0.3 * _rand(30 + i, 3, h, wd), 0, 1)).to(DEV) for i, (h, wd) in enumerate(sizes)]
+    m = DiTEncoder(cfg, compute_dtype=build).load_numpy(w).to(DEV).eval()
+    t = DetectorInputTransform(fixed_size=(size, size))
+    with torch.no_grad():
+        batch = t(imgs)[0].tensors
+        if build == "fp8":
+            m.calibrate_fp8(batch)
+        want = m(batch).hidden_states
+        got = t.encode(m, imgs).hidden_states
+        got16 = t.encode(m, [im.half() for im in imgs]).hidden_states
+        want16 = m(t([im.half() for im in imgs])[0].tensors).hidden_states
+    for tp in cfg.taps:
+        assert torch.equal(got[tp], want[tp]), (build, tp)
+        # fp16 images in -> fp16 taps out (as DiTEncoder.forward does for an fp16 batch): the fp32 taps of the two-step path, narrowed
+        assert got16[tp].dtype == torch.float16 and torch.equal(got16[tp], ops.narrow_f16(want16[tp].contiguous())), (build, tp)
+    m.train()
+    with pytest.raises(RuntimeError, match="inference entry"):
+        m.forward_image_list(imgs, size=(size, size))
+    with pytest.raises(ValueError, match="channel dimension"):
+        m.eval().forward_image_list([imgs[0][:2]], size=(size, size))
+
+
 def test_encoder_accepts_fp16_pixels_without_a_host_cast():
     """ref trainer.py:153-155: the trainer hands fp16 images to the model; the encoder widens them with its own kernel and
     returns fp16 hidden states."""
