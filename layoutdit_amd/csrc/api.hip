@@ -30,6 +30,22 @@ int ensure_dynamic_lds(const void *kern, int bytes, std::atomic<unsigned long lo
     return LDIT_OK;
 }
 
+int compute_units()
+{
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    const bool slot = dev >= 0 && dev < 64;
+    if (slot) {
+        const int c = cached[dev].load(std::memory_order_relaxed);
+        if (c > 0) return c;
+    }
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    if (slot) cached[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+
 namespace {
 DiagSwitches read_switches()
 {
@@ -42,6 +58,7 @@ DiagSwitches read_switches()
     d.gemm_tile = digit("LDIT_GEMM_TILE", 0, 7);
     if (const char *e = getenv("LDIT_GEMM_THIN_TILES")) d.thin_tiles = atol(e);
     d.panel_r16_vec = is("LDIT_PANEL_R16", 'v');
+    d.panel_persist = is("LDIT_GEMM_PERSIST", '1');
     d.bf16_tile = digit("LDIT_GEMM_BF16_TILE", 2, 7);
     d.bf16_tile_env = getenv("LDIT_GEMM_BF16_TILE") != nullptr;
     d.bf16_tr_tile = digit("LDIT_GEMM_BF16_TR_TILE", 0, 9);

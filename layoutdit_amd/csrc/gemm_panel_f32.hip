@@ -23,6 +23,13 @@
 //   * two LDS stages, branch-free k-tile body of four chunks pinned with sched_group_barrier: fragments of chunk c+1 are
 //     read under the MFMAs of chunk c, the DMA pieces of tile kt+1 are dribbled between the MFMAs of chunk 0, the
 //     hand-over barrier sits in front of the last chunk's MFMAs (same pipeline as gemm_f32.hip).
+//   * optional PERSISTENT tile loop (round 4, LDIT_GEMM_PERSIST=1; measured, NOT the default): a launch of more tiles than CUs
+//     (q|k|v: 2.95 rounds, fc1: 3.94) runs 256 workgroups that walk their tiles; after a tile's k-loop the first k-tile of the
+//     NEXT tile is DMA'd into the LDS stage the last hand-over freed, BEFORE the epilogue's stores are issued, so the next
+//     prologue and the drain of the stores overlap.  Bit-identical (tested) - and no faster: q|k|v 362.6 vs 353.1 us, fc1 470.5 vs
+//     472.9 us, layer 0.995x (profiles/r04_f32_persistent_ab.txt).  The hardware dispatcher already starts the next workgroup of
+//     a CU while the previous one's stores drain, and its dynamic order absorbs per-CU speed differences that a static walk
+//     turns into stragglers.  Kept selectable as evidence.
 //   * exact fp32: every output element is one fma chain over k in one fixed order, the same for both MFMA shapes, so a
 //     row's result does not depend on where in a block or batch it sits (tests/test_gpu_forward.py checks bit equality).
 #include <cstdlib>
@@ -175,15 +182,15 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
     unsigned long long st_clk1 = 0, st_clk2 = 0;
 #endif
 
-    // ---- block -> tile (XCD-aware, bijective; tiles of one A row-panel are consecutive) ---------------------------
+    // ---- slot -> tile (XCD-aware, bijective; tiles of one A row-panel are consecutive).  Slots = tiles; a workgroup walks the
+    // slots blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8 whenever it is smaller than the tile count, so a workgroup
+    // stays inside one XCD's chunk of tiles)
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
     const int ntiles = nbm * nbn;
-    int tile;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = ntiles >> 3, rr = ntiles & 7;
-        tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
-    }
-    const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+    auto tile_of = [&](int slot) {
+        const int xcd = slot & 7, idx = slot >> 3, qq = ntiles >> 3, rr = ntiles & 7;
+        return (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    };
 
     // ---- DMA sources: this wave moves pieces wave + 4u (8 rows x 128 B each).  Row-major operands: the tile origin
     // (m0 * lda, n0 * K) goes into the 64-bit wave-uniform base, only the offset INSIDE the tile (< 304 rows) is kept in
@@ -191,28 +198,34 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
     // so M * lda may be anything the 2^31-element host limit allows.  Patch mode keeps 32-bit ELEMENT offsets into the
     // image batch (host limit: B * in_ch * H * W < 2^31).
     unsigned src[NLD];
+    const float *a_tile, *w_tile;
+    int m0, n0;
+    auto setup = [&](int tile) {
+        m0 = (tile / nbn) * BM;
+        n0 = (tile % nbn) * BN;
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-        const int row = 8 * (wave + 4 * u) + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        if (8 * (wave + 4 * u) < BM) {
-            int gm = m0 + row;
-            gm = gm < p.M ? gm : p.M - 1;
-            if (AMODE == A_PATCH) {
-                const int b = gm / p.patches, pi = gm - b * p.patches;
-                const int gy = pi / p.gw, gx = pi - gy * p.gw;
-                src[u] = (unsigned)b * (unsigned)p.lda + (unsigned)(gy * p.patch * p.img_w + gx * p.patch);
+        for (int u = 0; u < NLD; ++u) {
+            const int row = 8 * (wave + 4 * u) + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            if (8 * (wave + 4 * u) < BM) {
+                int gm = m0 + row;
+                gm = gm < p.M ? gm : p.M - 1;
+                if (AMODE == A_PATCH) {
+                    const int b = gm / p.patches, pi = gm - b * p.patches;
+                    const int gy = pi / p.gw, gx = pi - gy * p.gw;
+                    src[u] = (unsigned)b * (unsigned)p.lda + (unsigned)(gy * p.patch * p.img_w + gx * p.patch);
+                } else {
+                    src[u] = ((unsigned)(gm - m0) * (unsigned)p.lda + c * 4) * 4u;      // BYTE offset inside the tile
+                }
             } else {
-                src[u] = ((unsigned)(gm - m0) * (unsigned)p.lda + c * 4) * 4u;      // BYTE offset inside the tile
+                int gn = n0 + row - BM;
+                gn = gn < p.N ? gn : p.N - 1;
+                src[u] = ((unsigned)(gn - n0) * (unsigned)p.K + c * 4) * 4u;            // BYTE offset inside the tile
             }
-        } else {
-            int gn = n0 + row - BM;
-            gn = gn < p.N ? gn : p.N - 1;
-            src[u] = ((unsigned)(gn - n0) * (unsigned)p.K + c * 4) * 4u;            // BYTE offset inside the tile
         }
-    }
-    const float *a_tile = AMODE == A_PATCH ? p.A : p.A + (size_t)m0 * (size_t)p.lda;
-    const float *w_tile = p.W + (size_t)n0 * (size_t)p.K;
+        a_tile = AMODE == A_PATCH ? p.A : p.A + (size_t)m0 * (size_t)p.lda;
+        w_tile = p.W + (size_t)n0 * (size_t)p.K;
+    };
     auto issue = [&](int stage, int k0) {
         char *base = smem + stage * STAGE_BYTES;
 #pragma unroll
@@ -236,11 +249,7 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
     };
 
     f32x16 acc32[T32 > 0 ? T32 : 1];
-    f32x4 acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int t = 0; t < T32; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc32[t][e] = 0.0f;
+    f32x4 acc16[2];
 
     const int nk = p.K / BK;
     const int sw32 = (c32 >> 1) & 7, sw16 = (c16 >> 1) & 7;
@@ -314,15 +323,25 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
     static_assert(NF <= NM, "fewer MFMAs than fragment reads in a chunk");
 
     Frags f0, f1;
+    int slot = blockIdx.x;
+    setup(tile_of(slot));
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tile has landed before anybody reads it
     __syncthreads();
 #ifdef LDIT_GEMM_STAMPS
     st_clk1 = __builtin_amdgcn_s_memtime();
 #endif
-    load_frags(0, 0, f0);
+    int flip = 0;                // physical stage of this tile's k-tile 0 (wave-uniform)
+    for (;;) {
+#pragma unroll
+    for (int t = 0; t < T32; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[t][e] = 0.0f;
+    acc16[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc16[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_frags(flip, 0, f0);
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+        const int cur = (kt & 1) ^ flip;
         const int knext = (kt + 1 < nk ? kt + 1 : nk - 1) * BK;
         __builtin_amdgcn_sched_barrier(0);
         // ---- chunk 0: MFMAs of f0 | read chunk 1 -> f1 | DMA tile kt+1 -> stage cur^1 (free since the last hand-over)
@@ -383,18 +402,41 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
 #ifdef LDIT_GEMM_STAMPS
     st_clk2 = __builtin_amdgcn_s_memtime();
 #endif
+    // ---- next tile's first k-tile -> the stage the last hand-over freed (every wave has passed that barrier, so nobody reads it
+    // any more; the other stage only feeds the discarded read-ahead of the last chunk), BEFORE this tile's stores are issued
+    const int em0 = m0, en0 = n0;
+    const int free_stage = ((nk - 1) & 1) ^ flip;
+    const int next_slot = slot + (int)gridDim.x;
+    const bool more = next_slot < ntiles;                                           // block-uniform
+    if (more) {
+        setup(tile_of(next_slot));
+        issue(free_stage, 0);
+    }
     // ---- epilogue ---------------------------------------------------------------------------------------------------
-    const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);                    // block-uniform
-    const int nw = n0 + wave * 32;
-    if (cols_in && m0 + BM <= p.M) {
-        if (p.Y2) store_panel<T32, HALF, EPI, 1, true>(p, acc32, acc16, m0, nw, lane);
-        else store_panel<T32, HALF, EPI, 1, false>(p, acc32, acc16, m0, nw, lane);
+    const bool cols_in = (en0 + BN <= p.N) && ((p.ldy & 3) == 0);                   // block-uniform
+    const int nw = en0 + wave * 32;
+    const bool interior = cols_in && em0 + BM <= p.M;
+    if (interior) {
+        if (p.Y2) store_panel<T32, HALF, EPI, 1, true>(p, acc32, acc16, em0, nw, lane);
+        else store_panel<T32, HALF, EPI, 1, false>(p, acc32, acc16, em0, nw, lane);
     } else if (cols_in) {
-        if (p.Y2) store_panel<T32, HALF, EPI, 2, true>(p, acc32, acc16, m0, nw, lane);
-        else store_panel<T32, HALF, EPI, 2, false>(p, acc32, acc16, m0, nw, lane);
+        if (p.Y2) store_panel<T32, HALF, EPI, 2, true>(p, acc32, acc16, em0, nw, lane);
+        else store_panel<T32, HALF, EPI, 2, false>(p, acc32, acc16, em0, nw, lane);
     } else {
-        if (p.Y2) store_panel<T32, HALF, EPI, 0, true>(p, acc32, acc16, m0, nw, lane);
-        else store_panel<T32, HALF, EPI, 0, false>(p, acc32, acc16, m0, nw, lane);
+        if (p.Y2) store_panel<T32, HALF, EPI, 0, true>(p, acc32, acc16, em0, nw, lane);
+        else store_panel<T32, HALF, EPI, 0, false>(p, acc32, acc16, em0, nw, lane);
+    }
+    if (!more) break;
+    // The next k-tile 0 must have landed before anybody reads it.  Vector-memory operations retire in issue order, and this wave
+    // issued at least 4 T32 store instructions (one 16-B store per accumulator quad of the 32-row tiles; global stores cannot be
+    // moved above the DMA, which reads global memory) AFTER its DMA pieces: "all but the youngest 4 T32 done" therefore covers every
+    // piece while the tail of the stores stays in flight under the next k-loop.  Any other epilogue shape drains everything.
+    if (interior && !p.Y2 && T32 > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * T32) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    flip = free_stage;
+    slot = next_slot;
     }
 #ifdef LDIT_GEMM_STAMPS
     if (p.stamps) {
@@ -404,7 +446,7 @@ __global__ void __launch_bounds__(256) gemm_panel_f32(const GemmArgs p)
         if (tid == 0) {
             unsigned long long *o = p.stamps + (size_t)blockIdx.x * 8;
             o[0] = st_real0; o[1] = st_real1; o[2] = st_clk1 - st_clk0; o[3] = st_clk2 - st_clk1; o[4] = st_clk3 - st_clk2;
-            o[5] = st_clk4 - st_clk3; o[6] = 0; o[7] = tile;
+            o[5] = st_clk4 - st_clk3; o[6] = 0; o[7] = slot;
         }
     }
 #endif
@@ -430,7 +472,10 @@ int launch_panel_v(const GemmArgs &a, hipStream_t stream)
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BNP - 1) / BNP);
     auto kern = gemm_panel_f32<T32, HALF, EPI, AMODE, R16VEC>;
     LDIT_DYN_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, stream, a);
+    // LDIT_GEMM_PERSIST=1: as many workgroups as fit the chip at once (one per CU at > 80 KB of LDS each, two below), each walking its tiles
+    const int resident = (lds > 80 * 1024 ? 1 : 2) * compute_units();
+    const int grid = (tiles > resident && diag().panel_persist) ? resident : tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }

@@ -39,6 +39,10 @@ int ensure_dynamic_lds(const void *kern, int bytes, std::atomic<unsigned long lo
         if (int rc__ = ::ldit::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (bytes), done__)) return rc__; \
     } while (0)
 
+// Compute units of the current device (hipDeviceAttributeMultiprocessorCount; 256 on MI355X), cached per device ordinal: the
+// persistent GEMM launches size their grid with it.  Read-mostly process state like the dynamic-LDS bits above.
+int compute_units();
+
 // Diagnostic switches (tests and experiments force every tiling through them; none is needed in production).  Read from the
 // environment ONCE, when the library is first used - not per launch (a getenv on the 12 us-per-launch serving path) - and
 // again only by ldit_debug_reload_env() (tests call it after changing a variable).
@@ -46,6 +50,7 @@ struct DiagSwitches {
     int gemm_tile = -1;          // LDIT_GEMM_TILE 0..7 (fp32 GEMM tiling)
     long thin_tiles = 192;       // LDIT_GEMM_THIN_TILES
     bool panel_r16_vec = false;  // LDIT_PANEL_R16=vec
+    bool panel_persist = false;  // LDIT_GEMM_PERSIST=1: persistent tile loop of the fp32 panel GEMM (measured equal: off by default)
     int bf16_tile = -1;          // LDIT_GEMM_BF16_TILE 2..5 (-1 = picker; any value also disables the small-M kernel)
     bool bf16_tile_env = false;  //   the variable is present at all
     int bf16_tr_tile = -1;       // LDIT_GEMM_BF16_TR_TILE

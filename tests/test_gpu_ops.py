@@ -131,6 +131,30 @@ def test_thin_tiling_is_bit_identical_to_the_big_tilings(M, N, K):
     np.testing.assert_array_equal(auto, outs["4"][0])
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(64 * 197, 768, 768, "3"), (20000, 384, 96, "3"), (9000, 640, 64, "6"), (30000, 256, 160, "7"), (5000, 136, 96, "5")])
+def test_persistent_panel_loop_is_bit_identical_to_one_tile_per_workgroup(M, N, K, tile):
+    """LDIT_GEMM_PERSIST=1 (round 4, measured equal and therefore not the default): the fp32 panel GEMM as 256 (or 512) workgroups
+    that walk their tiles, the next tile's first k-tile prefetched under the epilogue behind a counted vmcnt.  More tiles than
+    resident workgroups on every case here (several tiles per workgroup, ragged last row panel, ragged columns, odd and even
+    k-tile counts, every panel height, every epilogue): the bits must be those of the ordinary launch."""
+    x, w, b = _rand(41, M, K), _rand(42, N, K, scale=0.05), _rand(43, N, scale=0.1)
+    lam, r = np.abs(_rand(44, N)) * 0.3 + 0.05, _rand(45, M, N)
+    _lib.set_switch("LDIT_GEMM_TILE", tile)
+    outs = {}
+    for mode in (None, "1"):
+        _lib.set_switch("LDIT_GEMM_PERSIST", mode)
+        y0 = ops.linear(_dev(x), _dev(w), _dev(b))
+        y1 = ops.linear(_dev(x), _dev(w), _dev(b), epilogue=_lib.EPI_BIAS_GELU)
+        h, tap = _dev(r), torch.full((M, N), float("nan"), device=DEV)
+        ops.linear(_dev(x), _dev(w), _dev(b), epilogue=_lib.EPI_SCALE_RESID, lam=_dev(lam), residual=h, out=h, out2=tap)
+        outs[mode] = [t.cpu().numpy() for t in (y0, y1, h, tap)]
+    _lib.set_switch("LDIT_GEMM_PERSIST", None)
+    _lib.set_switch("LDIT_GEMM_TILE", None)
+    for got, want in zip(outs["1"], outs[None]):
+        np.testing.assert_array_equal(got, want)
+    assert rel_l2(outs["1"][0], oracle.linear(x, w, b)) < 1e-6
+
+
 @pytest.mark.parametrize("tile", ["auto", "0", "1", "2", "3", "4", "6"])
 def test_linear_row_strides_through_the_c_abi(tile):
     """lda > K and ldy > N (operands that are column slices of wider buffers: the fused q|k|v tensor, an output written into
