@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libldit_hip.so")
+# LDIT_LIB_PATH (diagnostic): load another BUILD of this same library - an A/B variant compiled with extra -D flags by
+# scripts/build_alt.sh - instead of the shipped one.  Still the HIP library or nothing: there is no other implementation.
+LIB_PATH = os.environ.get("LDIT_LIB_PATH") or os.path.join(_HERE, "libldit_hip.so")
 
 LDIT_ABI_VERSION = 5
 LDIT_MAX_TAPS = 8

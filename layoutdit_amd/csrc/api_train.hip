@@ -67,9 +67,13 @@ constexpr int MAX_SPLITS = 8;
 // Every split costs one more fp32 slab to write and to sum, hence as few as fill that round, at most 8.
 int pick_splits(int Mout, int Nout, int nk)
 {
+    // (Round 4, scripts/wgrad_tiles.py: timed alone, GEMM + slab sum, the eight-wave 256 x 256 tile with K cut six to eight ways
+    // wins - W2 / W1 [768 x 3072] 81.8 -> 71.4 us.  Inside the train step it loses: twice the slabs are twice the fp32 traffic of
+    // the reduction, which there runs from HBM - per layer wgrad 238 -> 223 us but slab sums 28 -> 53 us, whether they are
+    // queued or issued right behind their GEMM (profiles/r04_wgrad_tiles.txt).  Few splits on the small tile stay.)
     const long tiles = (long)((Mout + 127) / 128) * ((Nout + 127) / 128);
     int s = (int)(512 / tiles);
-    if (s > 8) s = 8;
+    if (s > MAX_SPLITS) s = MAX_SPLITS;
     if (s > nk) s = nk;
     if (s < 1) s = 1;
     while (s > 1 && ((nk + s - 1) / s) * (s - 1) >= nk) --s;      // no empty slab
@@ -107,7 +111,9 @@ TrainWs train_ws_map(const Geo &g, int batch)
     w.part_rows_ln = (size_t)layernorm_bwd_blocks((int64_t)M);
     const size_t widths[10] = {C, C, F, C, C, C, C, 3 * C, C, C};
     const bool ln[10] = {false, false, false, true, true, false, false, false, true, true};
-    for (int i = 0; i < 10; ++i) w.part[i] = take((ln[i] ? w.part_rows_ln : w.part_rows_tile) * widths[i] * 4);
+    (void)ln;
+    const size_t part_rows = std::max(std::max(w.part_rows_ln, w.part_rows_tile), (size_t)layernorm_bwd_resid_blocks((int64_t)M));     // every buffer fits any producer
+    for (int i = 0; i < 10; ++i) w.part[i] = take(part_rows * widths[i] * 4);
     w.total = o;
     return w;
 }
@@ -234,10 +240,10 @@ int wgrad(Probe &probe, ReduceJobs &jobs, const void *dY, int ld_dy, const void 
 
 // one dgrad:  dX[M, Kout] = epi( dY[M, Nred] . W[Nred, Kout] ), W the bf16 copy of the nn.Linear weight as stored
 int dgrad(Probe &probe, const void *dY, int Nred, const void *W, void *dX, int M, int Kout, int epi, const void *aux, const void *zeros,
-          hipStream_t stream)
+          hipStream_t stream, float *colsum = nullptr)
 {
     GemmExtra x{};
-    x.zeros = zeros; x.aux = aux; x.ldaux = Kout;
+    x.zeros = zeros; x.aux = aux; x.ldaux = Kout; x.colsum = colsum;
     LDIT_RUN(probe, LDIT_K_GEMM, launch_gemm_bf16_tr(dY, Nred, false, W, Kout, nullptr, dX, Kout, M, Kout, Nred, epi, x, stream));
     return LDIT_OK;
 }
@@ -277,6 +283,7 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, c
     const float *rowscale = drop_scales ? reinterpret_cast<const float *>(S + sm.rowscale) : nullptr;
     const float scale = 1.0f / sqrtf((float)g.D);
     const int rows_tile = (int)wm.part_rows_tile, rows_ln = (int)wm.part_rows_ln;
+    const int rows_lnr = C <= 1024 ? layernorm_bwd_resid_blocks((int64_t)M) : rows_ln;     // partial rows of the fused LayerNorm + LayerScale backward
     ReduceJobs jobs;
 
     if (stage_hi == g.L) LDIT_HIP_CHECK(hipMemsetAsync(dh, 0, act * 4, stream));
@@ -294,14 +301,17 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, c
         // ---- MLP branch:  h_out = h_mid + rs2 lam2 (.) (gelu(y2 W1^T + b1) W2^T + b2) --------------------------------
         LDIT_RUN(probe, LDIT_K_OTHER, launch_resid_bwd(dh, S + sl.z2, F32(pl.lam2), rs2, dz, nullptr, M, C, Mp, PART(0), PART(1), stream));
         LDIT_TRY(wgrad(probe, jobs, dz, C, S + sl.g, F, GR(gl.w2), reinterpret_cast<float *>(ws + wm.slab[0]), C, F, M, zeros, stream));
-        LDIT_TRY(dgrad(probe, dz, C, W16 + gl.w2 / 2, da1, M, F, EPI_GELU_BWD, S + sl.a1, zeros, stream));          // da1 = (dz W2) (.) gelu'
-        LDIT_RUN(probe, LDIT_K_OTHER, launch_colsum_bf16(da1, M, F, F, PART(2), stream));
+        // da1 = (dz W2) (.) gelu'; its column sums (the fc1 bias gradient) leave the same epilogue (F a multiple of 256), else a pass
+        const bool b1_fused = F % 256 == 0;
+        LDIT_TRY(dgrad(probe, dz, C, W16 + gl.w2 / 2, da1, M, F, EPI_GELU_BWD, S + sl.a1, zeros, stream, b1_fused ? PART(2) : nullptr));
+        if (!b1_fused) LDIT_RUN(probe, LDIT_K_OTHER, launch_colsum_bf16(da1, M, F, F, PART(2), stream));
         LDIT_TRY(wgrad(probe, jobs, da1, F, S + sl.y2, C, GR(gl.w1), reinterpret_cast<float *>(ws + wm.slab[1]), F, C, M, zeros, stream));
         LDIT_TRY(dgrad(probe, da1, F, W16 + gl.w1 / 2, dy, M, C, EPI_F32, nullptr, zeros, stream));
-        LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bwd(dy, reinterpret_cast<const float *>(S + sl.h_mid), F32(pl.ln2_w), dh, M, C,
-                                                              cfg->ln_eps, PART(3), PART(4), stream));
         // ---- attention branch:  h_mid = h_in + rs1 lam1 (.) (attn(LN1(h_in)) Wo^T + bo) --------------------------------
-        LDIT_RUN(probe, LDIT_K_OTHER, launch_resid_bwd(dh, S + sl.z1, F32(pl.lam1), rs1, dz, nullptr, M, C, Mp, PART(5), PART(6), stream));
+        // its LayerScale / residual backward rides in the LayerNorm backward that produces dh (h_mid): one pass, dh read once
+        LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bwd_resid(dy, reinterpret_cast<const float *>(S + sl.h_mid), F32(pl.ln2_w), dh, M, C,
+                                                                    cfg->ln_eps, PART(3), PART(4), S + sl.z1, F32(pl.lam1), rs1, dz, PART(5),
+                                                                    PART(6), stream));
         LDIT_TRY(wgrad(probe, jobs, dz, C, S + sl.o, C, GR(gl.wo), reinterpret_cast<float *>(ws + wm.slab[2]), C, C, M, zeros, stream));
         LDIT_TRY(dgrad(probe, dz, C, W16 + gl.wo / 2, dob, M, C, EPI_BIAS, nullptr, zeros, stream));
         {
@@ -320,11 +330,11 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, c
         if (jobs.n + 10 > 16) LDIT_RUN(probe, LDIT_K_OTHER, launch_reduce_jobs(jobs, stream));
         jobs.add(PART(0), GR(gl.lam2), C, rows_tile, C);
         jobs.add(PART(1), GR(gl.b2), C, rows_tile, C);
-        jobs.add(PART(2), GR(gl.b1), F, rows_tile, F);
-        jobs.add(PART(3), GR(gl.ln2_w), C, rows_ln, C);
-        jobs.add(PART(4), GR(gl.ln2_b), C, rows_ln, C);
-        jobs.add(PART(5), GR(gl.lam1), C, rows_tile, C);
-        jobs.add(PART(6), GR(gl.bo), C, rows_tile, C);
+        jobs.add(PART(2), GR(gl.b1), F, F % 256 == 0 ? gemm_bf16_tr_colsum_rows(M, F) : rows_tile, F);
+        jobs.add(PART(3), GR(gl.ln2_w), C, rows_lnr, C);
+        jobs.add(PART(4), GR(gl.ln2_b), C, rows_lnr, C);
+        jobs.add(PART(5), GR(gl.lam1), C, rows_lnr, C);
+        jobs.add(PART(6), GR(gl.bo), C, rows_lnr, C);
         jobs.add(PART(7), GR(gl.bqkv), 3 * C, rows_tile, 3 * C);
         jobs.add(PART(8), GR(gl.ln1_w), C, rows_ln, C);
         jobs.add(PART(9), GR(gl.ln1_b), C, rows_ln, C);

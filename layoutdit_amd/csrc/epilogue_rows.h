@@ -32,10 +32,14 @@ enum { EPI_OUT_BF16 = 0, EPI_OUT_FP8 = 1, EPI_OUT_F32 = 2,
 // the GELU derivative (aux).
 // L16: the accumulators are 2 TM x 2 TN tiles of 16 x 16 (v_mfma_f32_16x16x32_*: acc[i][j][e] = row 16 i + (lane & 15), column
 // 16 j + 4 (lane >> 4) + e) instead of TM x TN tiles of 32 x 32; only the write into the slab differs.
+// mrows: rows of the matrix (rows >= mrows are neither read nor written: the ragged last row tile may take this path too).
+// csum (gemm_bf16_tr.hip, bf16 output only): fp32 [.., ldy]: receives, at row 0, the column sums of the values this wave stores
+// (as rounded to bf16), rows < mrows only - the caller hands in the partial row of this (tile, wave row).
 template <int TM, int TN, int EPI, int OUT, bool L16 = false, typename ACC>
 __device__ __forceinline__ void store_rows_via_lds(const ACC &acc, char *buf, void *Yv, float *Y2, const float *R,
                                                    const float *bias, const float *lam, const float *wscale, int ldy, int mw,
-                                                   int nw, int lane, float ab, float oinv, const GemmExtra x = GemmExtra{})
+                                                   int nw, int lane, float ab, float oinv, const GemmExtra x = GemmExtra{},
+                                                   int mrows = 0x7fffffff, float *csum = nullptr)
 {
     static_assert(TN % 2 == 0, "slabs are 64 columns wide");
     const int c32 = lane & 31, h = lane >> 5;
@@ -46,6 +50,7 @@ __device__ __forceinline__ void store_rows_via_lds(const ACC &acc, char *buf, vo
         const unsigned n = (unsigned)(nw + 64 * jp + 4 * rq);
         const f32x4 biasq = bias ? *reinterpret_cast<const f32x4 *>(bias + n) : zero4;
         const f32x4 lamq = EPI == EPI_SCALE_RESID ? *reinterpret_cast<const f32x4 *>(lam + n) : zero4;
+        f32x4 colacc = {0.f, 0.f, 0.f, 0.f};
         f32x4 abq = {ab, ab, ab, ab};
         if (wscale) {
             const f32x4 w = *reinterpret_cast<const f32x4 *>(wscale + n);
@@ -76,6 +81,7 @@ __device__ __forceinline__ void store_rows_via_lds(const ACC &acc, char *buf, vo
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int row = 4 * r + rrow;
+                if (mw + 32 * i + row >= mrows) continue;
                 f32x4 v = *reinterpret_cast<const f32x4 *>(buf + row * EPI_ROW_BYTES + rq * 16);
                 unsigned o = (unsigned)(mw + 32 * i + row) * (unsigned)ldy + n;
 #pragma unroll
@@ -148,8 +154,23 @@ __device__ __forceinline__ void store_rows_via_lds(const ACC &acc, char *buf, vo
                 } else {
                     const epi_bf16x4 pk = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                     *reinterpret_cast<epi_bf16x4 *>(static_cast<__bf16 *>(Yv) + o) = pk;
+                    if (csum) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) colacc[e] += (float)pk[e];
+                    }
                 }
             }
+        }
+        if (OUT == EPI_OUT_BF16 && csum) {
+            // the four row groups (lane >> 4) of a column quad -> lane group 0, fixed order; one 16-B store per 64-column slab and lane
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = colacc[e];
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                colacc[e] = t;
+            }
+            if (rrow == 0) *reinterpret_cast<f32x4 *>(csum + n) = colacc;
         }
     }
 }

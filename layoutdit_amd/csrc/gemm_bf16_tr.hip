@@ -208,9 +208,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
 
     const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
-    if (cols_in && m0 + BM <= p.M) {
+    if (cols_in && (m0 + BM <= p.M || p.x.colsum)) {
+        // (with column sums requested the ragged last row tile takes the slab path too, rows past M skipped)
+        float *cs = (!f32_out<EPI>() && p.x.colsum) ? p.x.colsum + (size_t)((m0 / BM) * WM + wm) * (size_t)p.ldy : nullptr;
         store_rows_via_lds<TM, TN, EPI, f32_out<EPI>() ? EPI_OUT_F32 : EPI_OUT_BF16>(
-            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, nullptr, p.ldy, mw, nw, lane, 1.0f, 1.0f, p.x);
+            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, nullptr, p.ldy, mw, nw, lane, 1.0f, 1.0f, p.x, p.M, cs);
     } else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
     else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
 }
@@ -235,8 +237,10 @@ int launch_tr_tiled(const GemmArgsH &a, hipStream_t stream)
     // 256 x 256 (8 waves) when that fills most of a round, else 128 x 128 (4 waves, two workgroups per CU).  A K-contiguous A
     // operand (dgrad) may also take the 192- and 320-row tiles of gemm_bf16.hip against round quantisation: whole rounds of 256
     // workgroups, priced as rounds x tile height.
-    const long t256 = (long)a.x.splits * ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const long o256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const long t256 = (long)a.x.splits * o256;
     int pick = t256 >= 120 ? 3 : 2;
+    (void)o256;
     if (!TA && pick == 3) {
         double best = (double)((t256 + 255) / 256);
         for (int bm : {192, 320}) {
@@ -256,6 +260,25 @@ int launch_tr_tiled(const GemmArgsH &a, hipStream_t stream)
 
 }  // namespace
 
+// Partial rows a launch with GemmExtra::colsum writes for an M-row output (the tile height the launcher will pick for this shape
+// is a function of M, N alone): rows = row tiles x 2 wave rows; `bm` receives the tile height.
+int gemm_bf16_tr_colsum_rows(int M, int N, int *bm)
+{
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    int h = t256 >= 120 ? 256 : 128;
+    if (h == 256) {
+        double best = (double)((t256 + 255) / 256);
+        for (int b : {192, 320}) {
+            const long t = (long)((M + b - 1) / b) * ((N + 255) / 256);
+            const double c = (double)((t + 255) / 256) * (b / 256.0) * 1.03;
+            if (c < best) { best = c; h = b; }
+        }
+    }
+    if (const int force = diag().bf16_tr_tile; force >= 2 && force <= 5) h = force == 2 ? 128 : force == 3 ? 256 : force == 4 ? 192 : 320;
+    if (bm) *bm = h;
+    return ((M + h - 1) / h) * 2;
+}
+
 // Y[M, N] = epi( A . W ) with W [K rows (reduction), N cols] row stride ldw, and A either K-contiguous [M, K] (a_reduction_major
 // = false; K % 64 == 0) or reduction-major [K rows, M cols] (true; any K, rows past K read x.zeros).  lda / ldw multiples of 8,
 // M (when reduction-major) and N multiples of 8.  Epilogues: EPI_F32 (+ split-K), EPI_BIAS, EPI_GELU_BWD.
@@ -273,6 +296,8 @@ int launch_gemm_bf16_tr(const void *A, int lda, bool a_reduction_major, const vo
     GemmArgsH a{};
     a.A = static_cast<const bf16_t *>(A); a.W = static_cast<const bf16_t *>(W); a.Y = Y; a.bias = bias;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldy = ldy; a.x = x;
+    if (x.colsum && (a_reduction_major || epi == EPI_F32 || x.splits != 1 || (N % 256) || ldy != N || !aligned16(x.colsum)))
+        return fail(LDIT_EINVAL, "gemm_bf16_tr: column sums need the dgrad form with a bf16 output, N a multiple of 256 and ldy == N");
     if (a_reduction_major) {
         if (epi != EPI_F32) return fail(LDIT_EINVAL, "gemm_bf16_tr: wgrad form has the fp32 epilogue only");
         return launch_tr_tiled<EPI_F32, true>(a, stream);

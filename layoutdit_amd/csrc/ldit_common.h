@@ -163,6 +163,10 @@ struct GemmExtra {
     unsigned seg_a = 0, seg_w = 0;
     int seg_inner = 0;                 // 1: the segments are walked per 64-deep k-tile (k-tile outermost) instead of per whole K
     int nsplit_out = 0;                // EPI_GELU_SPLIT: planes of the output row (row stride ldy = nsplit_out * N)
+    // gemm_bf16_tr.hip (round 4): column sums of the bf16 OUTPUT as the epilogue writes it - the bias gradient that a separate pass
+    // over the tensor used to collect.  colsum[r][n], r = (row tile index * waves along M + wave row): one fp32 partial row per
+    // wave row of every tile, `colsum_rows(M, BM, WM)` of them, summed afterwards by launch_reduce_jobs; row stride = N.
+    float *colsum = nullptr;
 };
 
 // x ~= p[0] + p[1] (+ p[2]): the bf16 planes of the split-fp32 build.  Every subtraction is exact in fp32.
@@ -238,6 +242,7 @@ int launch_gemm_bf16_ex(const void *A, int lda, const void *W, const float *bias
                         const float *lam, const float *R, float *Y2, const GemmExtra &x, hipStream_t stream);
 int launch_gemm_bf16_tr(const void *A, int lda, bool a_reduction_major, const void *W, int ldw, const float *bias, void *Y, int ldy,
                         int M, int N, int K, int epi, const GemmExtra &x, hipStream_t stream);
+int gemm_bf16_tr_colsum_rows(int M, int N, int *bm = nullptr);     // partial rows written through GemmExtra::colsum
 int launch_cvt_bf16(const float *src, void *dst, size_t n, hipStream_t stream, float mul = 1.0f);
 // split-fp32 build: dst bf16 [rows, planes * cols] = the `planes` bf16 planes of src fp32 [rows, cols] (row stride lds) side by side
 int launch_split_planes(const float *src, int lds, void *dst, int rows, int cols, int planes, hipStream_t stream, float mul = 1.0f);
@@ -293,8 +298,12 @@ int launch_resid_bwd(const float *dh, const void *z, const float *lam, const flo
 int launch_colsum_bf16(const void *src, int M, int N, int ld, float *part, hipStream_t stream);   // part[ceil(M/64)][N]
 int launch_rows_to_bf16(const float *src, void *dst, int M, int N, int skip_tokens, hipStream_t stream);
 int layernorm_bwd_blocks(int64_t rows);
+int layernorm_bwd_resid_blocks(int64_t rows);
 int launch_layernorm_bwd(const float *dy, const float *x, const float *g, float *dh, int64_t rows, int C, float eps,
                          float *dg_part, float *db_part, hipStream_t stream);
+int launch_layernorm_bwd_resid(const float *dy, const float *x, const float *g, float *dh, int64_t rows, int C, float eps,
+                               float *dg_part, float *db_part, const void *z, const float *lam, const float *rowscale, void *dz,
+                               float *dlam_part, float *dzb_part, hipStream_t stream);
 int launch_add_inplace(float *a, const float *b, size_t n, hipStream_t stream);
 int launch_expand_rowscale(const float *drop, float *rowscale, int B, int T, int nvec, hipStream_t stream);
 int launch_embed_bwd_small(const float *dh0, float *dpos, float *dcls, float *dpb, int B, int T, int C, hipStream_t stream);

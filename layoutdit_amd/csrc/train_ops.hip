@@ -207,30 +207,53 @@ __global__ void __launch_bounds__(256) resid_bwd_tile(const float *__restrict__ 
 // from the saved LN input exactly as the forward computes them), a workgroup of 4 waves walks rows blk*4+w, +4*grid, ...
 // NWV waves per workgroup: 512 workgroups x 8 waves fill the chip at four waves per SIMD (C <= 1024); rows of up to 4096
 // floats keep 4 waves (498 registers, 128 KB of reduction buffer)
-template <int VPL, int NWV>
+// RES (round 4): the LayerScale + residual backward of the branch BELOW this LayerNorm (resid_bwd_tile's arithmetic: dz = dh' lam rs,
+// partial sums of dz and of dh' z rs) applied to the row while its new residual gradient dh' is still in registers - the
+// attention branch's resid_bwd behind layernorm_after's backward.  Saves a launch and one fp32 read of dh per layer; the partial
+// sums come out per workgroup (layernorm_bwd_blocks rows) like dgamma / dbeta, through the same LDS buffer in a second round.
+struct ResidFused {
+    const bf16_t *z;          // [rows, C] pre-LayerScale branch output saved by the forward
+    const float *lam;         // [C]
+    const float *rowscale;    // [rows] stochastic-depth factors or null
+    bf16_t *dz;               // [rows, C] out
+    float *dlam_part, *dzb_part;   // [blocks, C] out
+};
+
+template <int VPL, int NWV, bool RES>
 __global__ void __launch_bounds__(64 * NWV) layernorm_bwd_rows(const float *__restrict__ dy, const float *__restrict__ x,
                                                           const float *__restrict__ g, float *__restrict__ dh, int64_t rows,
                                                           int C, float eps, float *__restrict__ dg_part,
-                                                          float *__restrict__ db_part)
+                                                          float *__restrict__ db_part, const ResidFused rf)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_ln[];
     float *red = reinterpret_cast<float *>(smem_ln);          // [2][NWV][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = C >> 2;
     const float inv_c = 1.0f / (float)C;
+    // RES: gamma and lambda are re-read per row (3 KB vectors, L1 hits) instead of living in 2 VPL register quads: with them the
+    // kernel needs 160 VGPRs - three waves per SIMD, i.e. ONE eight-wave workgroup per CU instead of two, and the rows in flight
+    // that hide the memory round trip halve (measured: 47 us against 28 + 16 for the two separate kernels)
     f32x4 gg[VPL], sg[VPL], sb[VPL];
+    f32x4 sa[RES ? VPL : 1], sq[RES ? VPL : 1];
 #pragma unroll
     for (int u = 0; u < VPL; ++u) {
         const int idx = lane + 64 * u;
-        gg[u] = idx < nvec ? reinterpret_cast<const f32x4 *>(g)[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!RES) gg[u] = idx < nvec ? reinterpret_cast<const f32x4 *>(g)[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
         sg[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         sb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (RES) {
+            sa[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            sq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
     for (int64_t row = (int64_t)blockIdx.x * NWV + wave; row < rows; row += (int64_t)gridDim.x * NWV) {
         const f32x4 *x4 = reinterpret_cast<const f32x4 *>(x + row * C);
         const f32x4 *d4 = reinterpret_cast<const f32x4 *>(dy + row * C);
         f32x4 *h4 = reinterpret_cast<f32x4 *>(dh + row * C);
         f32x4 v[VPL], d[VPL], acc[VPL];             // dh is fetched with x and dy: one memory round trip per row, not two
+        bf16x4 zr[RES ? VPL : 1];
+        const f32x4 *gp = reinterpret_cast<const f32x4 *>(g), *lp = reinterpret_cast<const f32x4 *>(rf.lam);
+        if (RES) asm volatile("" : "+s"(gp), "+s"(lp));      // opaque per row: keeps the loads in the loop (see above)
         float s = 0.0f;
 #pragma unroll
         for (int u = 0; u < VPL; ++u) {
@@ -239,6 +262,10 @@ __global__ void __launch_bounds__(64 * NWV) layernorm_bwd_rows(const float *__re
                 v[u] = x4[idx];
                 d[u] = d4[idx];
                 acc[u] = h4[idx];
+                if (RES) {
+                    zr[u] = reinterpret_cast<const bf16x4 *>(rf.z + row * C)[idx];
+                    gg[u] = gp[idx];
+                }
                 s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
             } else {
                 v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -282,6 +309,21 @@ __global__ void __launch_bounds__(64 * NWV) layernorm_bwd_rows(const float *__re
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] += rstd * (d[u][e] * gg[u][e] - m1 - v[u][e] * m2);
                 h4[idx] = o;
+                if (RES) {
+                    // resid_bwd_tile's statements on the fresh dh row: g = dh rs, dz = g lam (bf16), sums of dz and of g z
+                    const float rs = rf.rowscale ? rf.rowscale[row] : 1.0f;
+                    const f32x4 l4 = lp[idx];
+                    bf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gr = o[e] * rs;
+                        const float a = gr * l4[e];
+                        pk[e] = (bf16_t)a;
+                        sa[u][e] += a;
+                        sq[u][e] += gr * (float)zr[u][e];
+                    }
+                    reinterpret_cast<bf16x4 *>(rf.dz + row * C)[idx] = pk;
+                }
             }
         }
     }
@@ -304,6 +346,28 @@ __global__ void __launch_bounds__(64 * NWV) layernorm_bwd_rows(const float *__re
         }
         dg_part[(size_t)blockIdx.x * C + c] = a;
         db_part[(size_t)blockIdx.x * C + c] = b;
+    }
+    if (RES) {
+        __syncthreads();            // the buffer is read out: second round for the LayerScale sums
+#pragma unroll
+        for (int u = 0; u < VPL; ++u) {
+            const int idx = lane + 64 * u;
+            if (idx < nvec) {
+                reinterpret_cast<f32x4 *>(red + (0 * NWV + wave) * C)[idx] = sa[u];
+                reinterpret_cast<f32x4 *>(red + (1 * NWV + wave) * C)[idx] = sq[u];
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 64 * NWV) {
+            float a = 0.0f, b = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) {
+                a += red[(0 * NWV + w) * C + c];
+                b += red[(1 * NWV + w) * C + c];
+            }
+            rf.dzb_part[(size_t)blockIdx.x * C + c] = a;
+            rf.dlam_part[(size_t)blockIdx.x * C + c] = b;
+        }
     }
 }
 
@@ -591,23 +655,52 @@ int launch_rows_to_bf16(const float *src, void *dst, int M, int N, int skip_toke
 // the waves beside it, not inside it - and 512 partial rows per gradient vector (1024 four-wave workgroups hid it as well but
 // doubled the second-stage reduction)
 int layernorm_bwd_blocks(int64_t rows) { return (int)(rows < 8 * 512 ? (rows + 7) / 8 : 512); }
+// the fused LayerNorm + LayerScale backward runs four-wave workgroups, three per CU (C <= 1024; wider rows keep the layout above)
+int layernorm_bwd_resid_blocks(int64_t rows) { return (int)(rows < 4 * 768 ? (rows + 3) / 4 : 768); }
 
-int launch_layernorm_bwd(const float *dy, const float *x, const float *g, float *dh, int64_t rows, int C, float eps,
-                         float *dg_part, float *db_part, hipStream_t stream)
+template <bool RES>
+static int launch_layernorm_bwd_t(const float *dy, const float *x, const float *g, float *dh, int64_t rows, int C, float eps,
+                                  float *dg_part, float *db_part, const ResidFused &rf, hipStream_t stream)
 {
     if (rows <= 0 || C <= 0) return fail(LDIT_EINVAL, "layernorm_bwd: empty problem");
     if ((C & 3) || C > 4096) return fail(LDIT_EUNSUPPORTED, "layernorm_bwd: C=%d must be a multiple of 4, at most 4096", C);
     if (!dy || !x || !g || !dh || !dg_part || !db_part) return fail(LDIT_EINVAL, "layernorm_bwd: null operand");
-    const int blocks = layernorm_bwd_blocks(rows);
-    const size_t lds = (size_t)2 * (C <= 1024 ? 8 : 4) * C * sizeof(float);
-    if (C <= 256) LAUNCH_CHECKED((layernorm_bwd_rows<1, 8>), dim3(blocks), dim3(512), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
-    else if (C <= 768) LAUNCH_CHECKED((layernorm_bwd_rows<3, 8>), dim3(blocks), dim3(512), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
-    else if (C <= 1024) LAUNCH_CHECKED((layernorm_bwd_rows<4, 8>), dim3(blocks), dim3(512), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
+    if (RES && (!rf.z || !rf.lam || !rf.dz || !rf.dlam_part || !rf.dzb_part || (reinterpret_cast<uintptr_t>(rf.z) & 7u) ||
+                (reinterpret_cast<uintptr_t>(rf.dz) & 7u) || !aligned16(rf.lam)))
+        return fail(LDIT_EINVAL, "layernorm_bwd: fused LayerScale operands null or misaligned");
+    const int blocks = (RES && C <= 1024) ? layernorm_bwd_resid_blocks(rows) : layernorm_bwd_blocks(rows);
+    const size_t lds = (size_t)2 * ((C <= 1024 && !RES) ? 8 : 4) * C * sizeof(float);
+    if (RES && C <= 1024) {
+        // fused form: 145 - 180 VGPRs = three / two waves per SIMD, so FOUR-wave workgroups (three / two per CU) keep the CU full
+        if (C <= 256) LAUNCH_CHECKED((layernorm_bwd_rows<1, 4, RES>), dim3(blocks), dim3(256), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part, rf);
+        else if (C <= 768) LAUNCH_CHECKED((layernorm_bwd_rows<3, 4, RES>), dim3(blocks), dim3(256), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part, rf);
+        else LAUNCH_CHECKED((layernorm_bwd_rows<4, 4, RES>), dim3(blocks), dim3(256), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part, rf);
+    } else if (C <= 256) LAUNCH_CHECKED((layernorm_bwd_rows<1, 8, RES>), dim3(blocks), dim3(512), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part, rf);
+    else if (C <= 768) LAUNCH_CHECKED((layernorm_bwd_rows<3, 8, RES>), dim3(blocks), dim3(512), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part, rf);
+    else if (C <= 1024) LAUNCH_CHECKED((layernorm_bwd_rows<4, 8, RES>), dim3(blocks), dim3(512), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part, rf);
     else {
-        LDIT_DYN_LDS((layernorm_bwd_rows<16, 4>), 2 * 4 * 4096 * 4);
-        LAUNCH_CHECKED((layernorm_bwd_rows<16, 4>), dim3(blocks), dim3(256), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part);
+        LDIT_DYN_LDS((layernorm_bwd_rows<16, 4, RES>), 2 * 4 * 4096 * 4);
+        LAUNCH_CHECKED((layernorm_bwd_rows<16, 4, RES>), dim3(blocks), dim3(256), lds, stream, dy, x, g, dh, rows, C, eps, dg_part, db_part, rf);
     }
     return LDIT_OK;
+}
+
+int launch_layernorm_bwd(const float *dy, const float *x, const float *g, float *dh, int64_t rows, int C, float eps,
+                         float *dg_part, float *db_part, hipStream_t stream)
+{
+    return launch_layernorm_bwd_t<false>(dy, x, g, dh, rows, C, eps, dg_part, db_part, ResidFused{}, stream);
+}
+
+// LayerNorm backward + the LayerScale / residual backward of the branch below it (dz, and the partial sums of dz and of dh z rs per
+// workgroup: layernorm_bwd_blocks(rows) partial rows each) in one pass over the rows
+int launch_layernorm_bwd_resid(const float *dy, const float *x, const float *g, float *dh, int64_t rows, int C, float eps,
+                               float *dg_part, float *db_part, const void *z, const float *lam, const float *rowscale, void *dz,
+                               float *dlam_part, float *dzb_part, hipStream_t stream)
+{
+    ResidFused rf;
+    rf.z = static_cast<const bf16_t *>(z); rf.lam = lam; rf.rowscale = rowscale; rf.dz = static_cast<bf16_t *>(dz);
+    rf.dlam_part = dlam_part; rf.dzb_part = dzb_part;
+    return launch_layernorm_bwd_t<true>(dy, x, g, dh, rows, C, eps, dg_part, db_part, rf, stream);
 }
 
 int launch_reduce_jobs(ReduceJobs &jobs, hipStream_t stream)

@@ -496,10 +496,12 @@ def colamax(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _splits_for(K: int, tiles: int) -> int:
-    """K-splits of a wgrad GEMM: enough workgroups for the machine (~512 / output tiles), every split non-empty."""
+def _splits_for(K: int, M: int, N: int) -> int:
+    """K-splits of a wgrad GEMM with an [M, N] output - the rule of csrc/api_train.hip pick_splits: enough 128 x 128 tiles for the
+    machine (~512 / output tiles, at most 8), every split non-empty."""
     nk = (K + 63) // 64
-    s = max(1, min(nk, 512 // max(tiles, 1)))
+    t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    s = max(1, min(nk, 8, 512 // max(t128, 1)))
     while s > 1 and ((nk + s - 1) // s) * (s - 1) >= nk:
         s -= 1
     return s
@@ -517,7 +519,7 @@ def wgrad_bf16(a: torch.Tensor, w: torch.Tensor, K: int, w_row_offset: int = 0) 
         raise ValueError("wgrad_bf16: K rows are not available in both operands")
     M, N = a.shape[1], w.shape[1]
     dev = _device(a, w)
-    splits = _splits_for(K, ((M + 127) // 128) * ((N + 127) // 128))
+    splits = _splits_for(K, M, N)
     slabs = torch.empty((splits, M, N), device=dev, dtype=torch.float32)
     _launch(_device(a, w), lib.ldit_linear_bf16_tr, a.data_ptr(), M, 1, w[w_row_offset:].data_ptr(), N, slabs.data_ptr(), N, M, N, K,
             _lib.EPI_F32, None, splits, _zero_page(dev).data_ptr())
