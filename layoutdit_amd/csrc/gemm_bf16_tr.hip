@@ -14,10 +14,13 @@
 // the row stride is a multiple of 256 bytes).
 // Reduction rows past the end (tokens are not a multiple of 64) are fetched from a page of zeros: LDS-DMA has no predication.
 //
-// Deliberately simple main loop (two LDS stages, one barrier per 64-deep k-tile, fragments of step s+1 read under the MFMAs
-// of step s, two waves per SIMD to cover each other): these GEMMs have K = tokens (12 608) or outputs >= 768, the k-loop
-// is long and its fixed costs small.  Same swapped-operand accumulator layout and epilogues as gemm_bf16.hip
-// (fp32 / split-K slabs, bf16, dgrad x saved GELU derivative).
+// Main loop (round 4: the pipeline of gemm_bf16.hip; rounds 2-3 ran a simple issue-all / read / multiply / barrier loop that left the
+// matrix pipe idle through every DMA burst, every hand-over and the first fragment reads behind it - the dgrad of fc2 took 115 us
+// where the forward GEMM of the same shape takes 72): two LDS stages, ONE barrier per 64-deep k-tile placed in front of the last
+// 16-deep step, whose MFMAs run while the first fragments of the next tile are read and the DMA of the tile after it is issued
+// into the stage the barrier just freed; on the eight-wave tiles one wave per SIMD issues the pieces (its partner's MFMAs cover
+// the issue stalls).  Same swapped-operand accumulator layout and epilogues as gemm_bf16.hip (fp32 / split-K slabs, bf16, dgrad x
+// saved GELU derivative, column sums).
 #include <cstdlib>
 
 #include "gemm_bf16_common.h"
@@ -34,10 +37,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
 {
     GemmArgsH p = p0;
     constexpr int NWAVES = WM * WN;
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, NLD = (BM + BN) / (8 * NWAVES);
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A_BYTES = BM * ROWB, STAGE = (BM + BN) * ROWB;
     static_assert((!TA || BM == 128 || BM == 256) && (BN == 128 || BN == 256), "reduction-major images need 256- or 512-byte rows");
-    static_assert((BM + BN) % (8 * NWAVES) == 0, "DMA pieces must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -56,24 +58,37 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
     if (EPI == EPI_F32 && p.x.splits > 1) {
         const int split = tile / ntiles, per = (nk + p.x.splits - 1) / p.x.splits, kt0 = split * per;
         tile -= split * ntiles;
-        nk = nk - kt0 < per ? nk - kt0 : per;
+        nk = __builtin_amdgcn_readfirstlane(nk - kt0 < per ? nk - kt0 : per);      // scalar from here on, like kbeg (k_of below feeds the DMA's scalar base)
         kbeg = __builtin_amdgcn_readfirstlane(kt0 * BKB);      // scalar from here on (the split index comes out of a vector-unit division)
         p.Y = static_cast<float *>(p.Y) + (size_t)split * (size_t)p.M * (size_t)p.ldy;
     }
     const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
 
-    // ---- DMA geometry of this lane's pieces (piece = wave + NWAVES u; 8 * piece < BM: A operand, else W) -----------------
-    unsigned src[NLD];      // element offset of the lane's 16-byte chunk at reduction row 0 / k = 0 of the tile
-    int krow[NLD];          // reduction row inside the k-tile (reduction-major pieces only)
+    // ---- DMA geometry of this lane's pieces (8 * piece < BM: A operand, else W).  Eight-wave tiles: waves 0..3 - one per SIMD -
+    // issue all of them (piece = wave + 4 u), waves 4..7 none: a piece holds its issuing wave for tens of cycles, which the SIMD
+    // partner's MFMAs cover (gemm_bf16.hip, profiles/r02_dma_issue.txt).  The 320-row tile keeps all eight waves issuing (registers).
+    constexpr bool SPLIT = NWAVES == 8 && TM < 5;
+    constexpr int LW = SPLIT ? 4 : NWAVES;
+    constexpr int NLW = (BM + BN) / (8 * LW);
+    static_assert((BM + BN) % (8 * LW) == 0, "DMA pieces must split evenly over the issuing waves");
+    const bool loader = !SPLIT || wave < LW;                  // wave-uniform
+    unsigned src[NLW];      // element offset of the lane's 16-byte chunk at reduction row 0 / k = 0 of the tile
+    auto piece_of = [&](int u) { return (wave % LW) + LW * u; };
+    // reduction row inside the k-tile of a reduction-major piece (only the ragged last k-tile asks)
+    auto krow_of = [&](int u) {
+        const int piece = piece_of(u);
+        const bool isA = 8 * piece < BM;
+        const int BT = isA ? BM : BN, cpr = BT / 8, pa = isA ? piece : piece - BM / 8;
+        return pa * (1024 / (BT * 2)) + lane / cpr;
+    };
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-        const int piece = wave + NWAVES * u;
+    for (int u = 0; u < NLW; ++u) {
+        const int piece = piece_of(u);
         if (!TA && 8 * piece < BM) {
             const int row = 8 * piece + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
             int gm = m0 + row;
             gm = gm < p.M ? gm : p.M - 1;
             src[u] = (unsigned)gm * (unsigned)p.lda + c * 8;
-            krow[u] = 0;
         } else {
             const bool isA = 8 * piece < BM;
             const int BT = isA ? BM : BN, cpr = BT / 8, pa = isA ? piece : piece - BM / 8;
@@ -82,7 +97,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
             const int ncols = isA ? p.M : p.N;
             col = col + 8 <= ncols ? col : ncols - 8;         // columns past the matrix: duplicates, discarded by the epilogue
             src[u] = (unsigned)kr * (unsigned)(isA ? p.lda : p.ldw) + (unsigned)col;
-            krow[u] = kr;
         }
     }
     auto issue = [&](int stage, int k0) {                     // k0: first reduction index of the k-tile
@@ -98,8 +112,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
             // pointers: no v_readfirstlane result reaches the DMA's scalar base within its five wait states, cdna guide 5.7 item 2)
             const bf16_t *a_k = p.A + (unsigned)k0, *a_r = p.A + (size_t)k0 * (size_t)p.lda, *w_r = p.W + (size_t)k0 * (size_t)p.ldw;
 #pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const int piece = wave + NWAVES * u;
+            for (int u = 0; u < NLW; ++u) {
+                const int piece = piece_of(u);
                 const bool isA = 8 * piece < BM;
                 glds16h_sbase((!TA && isA) ? a_k : isA ? a_r : w_r, 2u * src[u], dst + piece * 1024);
             }
@@ -107,8 +121,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
         }
 #endif
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int piece = wave + NWAVES * u;
+        for (int u = 0; u < NLW; ++u) {
+            const int piece = piece_of(u);
             const bf16_t *g;
             if (!TA && 8 * piece < BM) {
                 g = p.A + (src[u] + (unsigned)k0);
@@ -116,7 +130,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
                 const bool isA = 8 * piece < BM;
                 const bf16_t *opnd = isA ? p.A : p.W;
                 g = opnd + ((size_t)k0 * (size_t)(isA ? p.lda : p.ldw) + src[u]);
-                if (ragged && k0 + krow[u] >= p.K) g = static_cast<const bf16_t *>(p.x.zeros) + 8 * (lane & 7);
+                if (ragged && k0 + krow_of(u) >= p.K) g = static_cast<const bf16_t *>(p.x.zeros) + 8 * (lane & 7);
             }
             glds16h(g, base + piece * 1024);
         }
@@ -178,17 +192,22 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
     };
 
     bf16x8 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
-    issue(0, kbeg);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tile has landed before anybody reads it
+    // k-tile kt of this block -> its first reduction index (past the end: the last tile again - fetched, never multiplied)
+    auto k_of = [&](int kt) { return kbeg + (kt < nk ? kt : nk - 1) * BKB; };
+    if (loader) {
+        issue(0, k_of(0));
+        issue(1, k_of(1));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tiles have landed before anybody reads them
     __syncthreads();
+    load_frags(0, 0, xa0, wb0);
+    // the transposing reads are asm (hipcc would guard the builtin against the in-flight LDS-DMA with vmcnt(0)): every group of
+    // reads is waited for by hand BEHIND the MFMAs issued after it, and the next step's MFMAs are pinned behind that wait
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) issue(cur ^ 1, kbeg + (kt + 1) * BKB);          // lands while this k-tile is multiplied
-        load_frags(cur, 0, xa0, wb0);
-        // the transposing reads are asm (hipcc would guard the builtin against the in-flight LDS-DMA with vmcnt(0)): wait
-        // for them by hand, and pin the MFMAs behind the wait
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        // ---- steps 0 .. 2: multiply the fragments read during the previous step, read the next ones
         load_frags(cur, 1, xa1, wb1);
         mfma_step(xa0, wb0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -199,12 +218,20 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
         __builtin_amdgcn_sched_barrier(0);
         load_frags(cur, 3, xa1, wb1);
         mfma_step(xa0, wb0);
+        // ---- hand-over: own DMA of tile kt+1 landed (vmcnt 0), own reads of stage cur done (lgkmcnt 0), then all waves
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- step 3: the last fragments' MFMAs | first fragments of tile kt+1 | DMA of tile kt+2 -> stage cur (free now)
+        load_frags(cur ^ 1, 0, xa0, wb0);
+        if (loader) issue(cur, k_of(kt + 2));
+        mfma_step(xa1, wb1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        mfma_step(xa1, wb1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: do not rely on hipcc to drain the LDS-DMA in front of the barrier
-        __syncthreads();            // own DMA of tile kt+1 landed (vmcnt 0), every wave done reading stage cur
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-fetches of the tail must not outlive the LDS allocation
+    __syncthreads();                                      // every wave is out of the k-loop: the stage memory becomes slab buffers
 
     const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
@@ -241,15 +268,13 @@ int launch_tr_tiled(const GemmArgsH &a, hipStream_t stream)
     const long t256 = (long)a.x.splits * o256;
     int pick = t256 >= 120 ? 3 : 2;
     (void)o256;
-    if (!TA && pick == 3) {
-        double best = (double)((t256 + 255) / 256);
-        for (int bm : {192, 320}) {
-            const long t = (long)((a.M + bm - 1) / bm) * ((a.N + 255) / 256);
-            const double c = (double)((t + 255) / 256) * (bm / 256.0) * 1.03;
-            if (c < best) { best = c; pick = bm == 192 ? 4 : 5; }
-        }
+    // (wgrad form, round 4: a 256 x 128 eight-wave tile - one workgroup per CU, one DMA-issuing wave per SIMD - is selectable
+    //  (LDIT_GEMM_BF16_TR_TILE=6).  Alone it beats the 128 x 128 tiles at the same split counts by 1 - 3 %; inside the train step it
+    //  lost 5 % (75.6 vs ~70 us per call: profiles/r04_wgrad_tiles.txt), so two four-wave workgroups per CU stay the choice.)
+    if (const int force = diag().bf16_tr_tile; force >= 2 && (force <= (TA ? 3 : 5) || (TA && force == 6))) pick = force;
+    if constexpr (TA) {
+        if (pick == 6) return launch_tr<4, 2, 2, 2, EPI, TA>(a, stream);     // 256 x 128, 4 x 2 waves of 64 x 64
     }
-    if (const int force = diag().bf16_tr_tile; force >= 2 && force <= (TA ? 3 : 5)) pick = force;
     if constexpr (!TA) {
         if (pick == 4) return launch_tr<2, 4, 3, 2, EPI, TA>(a, stream);
         if (pick == 5) return launch_tr<2, 4, 5, 2, EPI, TA>(a, stream);

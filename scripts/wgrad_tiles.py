@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """wgrad form of gemm_bf16_tr (both operands reduction-major, K = tokens split over workgroups) on the ViT-B bs=64 shapes: time of
-the GEMM + the slab reduction per (tile, splits) choice.  LDIT_GEMM_BF16_TR_TILE: 2 = 128 x 128 (4 waves, two per CU), 3 = 256 x 256."""
+the GEMM + the slab reduction per (tile, splits) choice.  LDIT_GEMM_BF16_TR_TILE: 2 = 128 x 128 (4 waves, two per CU), 3 = 256 x 256, 6 = 256 x 128 (8 waves)."""
 import os, sys, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,7 +22,7 @@ for name, M, N in (("W2 [768 x 3072]", 768, 3072), ("W1 [3072 x 768]", 3072, 768
     w = torch.randn(K, N, device="cuda").to(torch.bfloat16)
     ref = None
     res = []
-    for tile in ("2", "3"):
+    for tile in ("2", "3", "6"):
         _lib.set_switch("LDIT_GEMM_BF16_TR_TILE", tile)
         for splits in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12):
             nk = (K + 63) // 64
