@@ -82,7 +82,13 @@ class DiTEncoder(nn.Module):
         gradients / master parameters - what the reference's CUDA branch does with fp16 autocast + GradScaler
         (trainer.py:168,177-180; bf16 needs no loss scaling, a scaled loss passes through unharmed) and within the
         bf16 gate of its fp32 CPU branch (trainer.py:171-172; gradients rel-L2 <= 3e-2 per tensor, measured <= 1e-2:
-        tests/test_gpu_train.py).  The ``"fp8"`` build is inference only."""
+        tests/test_gpu_train.py).  The ``"fp8"`` build is inference only.
+
+        ACTIVATION: HF's ``hidden_act="gelu"`` is the exact erf-GELU.  The ``"f32"`` / ``"f32x3"`` / ``"f32x6"`` inference forwards
+        evaluate it (< 1 ulp); the bf16 / fp8 inference forwards and EVERY training forward evaluate its logistic form
+        ``v * sigmoid(1.5958 v + 0.07136 v^3)`` (|deviation| <= 4.8e-4, below the bf16 rounding that follows) and the backward
+        differentiates that same function.  An ``"f32"`` model therefore trains through a (slightly) different activation, on bf16
+        operands, than its eval forward computes - inside the stated gates, documented here and in INTEGRATION.md."""
         super().__init__()
         if compute_dtype not in _DTYPES:
             raise ValueError(f"compute_dtype {compute_dtype!r}: expected 'f32', 'f32x3', 'f32x6', 'bf16' or 'fp8'")
