@@ -256,18 +256,14 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
 #pragma unroll
                             for (int r = 0; r < 16; ++r) s[kt][r] -= d;
                     }
-                    // row sum on PAIRS (v_pk_add_f32: 16 instead of 32 adds per chunk, and two short chains instead of one long one)
-                    f32x2 ls2 = {0.0f, 0.0f};
 #pragma unroll
                     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                        for (int r = 0; r < 16; r += 2) {
-                            const f32x2 pv = {__builtin_amdgcn_exp2f(s[kt][r]), __builtin_amdgcn_exp2f(s[kt][r + 1])};
-                            s[kt][r] = pv[0];
-                            s[kt][r + 1] = pv[1];
-                            ls2 += pv;
+                        for (int r = 0; r < 16; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(s[kt][r]);
+                            s[kt][r] = pv;
+                            lsum += pv;
                         }
-                    lsum = ls2[0] + ls2[1];
                 } else {
                 const bool grow = mx > m_run + lazy;
                 if (__builtin_amdgcn_ballot_w64(grow)) {
@@ -279,18 +275,14 @@ __global__ void __launch_bounds__(NW * 64, KT == 2 ? 4 : 2) attention_bf16(const
                     for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
                 }
                 const float mc = m_run * c;
-                f32x2 ls2 = {0.0f, 0.0f};
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const f32x2 pv = {__builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c, -mc)),
-                                          __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r + 1], c, -mc))};
-                        s[kt][r] = pv[0];
-                        s[kt][r + 1] = pv[1];
-                        ls2 += pv;
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c, -mc));
+                        s[kt][r] = pv;
+                        lsum += pv;
                     }
-                lsum = ls2[0] + ls2[1];
                 }
                 l_run += lsum;
                 ATT_STAMP(t4);

@@ -207,17 +207,14 @@ __global__ void __launch_bounds__(NW * 64, 2) attention_planes(const bf16_t *__r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[kt][r] -= d;
         }
-        f32x2 ls2 = {0.0f, 0.0f};            // row sum on pairs: v_pk_add_f32, two short chains (attention_bf16.hip)
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 pv = {__builtin_amdgcn_exp2f(s[kt][r]), __builtin_amdgcn_exp2f(s[kt][r + 1])};
-                s[kt][r] = pv[0];
-                s[kt][r + 1] = pv[1];
-                ls2 += pv;
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[kt][r]);
+                s[kt][r] = pv;
+                lsum += pv;
             }
-        lsum = ls2[0] + ls2[1];
         l_run += lsum;
         // ---- O^T += V^T . P^T over the plane products ----------------------------------------------------------------------------
         const unsigned vaddr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) const char *)(Vs + vlane));
