@@ -259,7 +259,7 @@ def split_fp32_lines(cfg, weights, x, ref_out, steps, warmup, dev):
                    "rel_l2_vs_headline_taps": [float(f"{e:.3e}") for e in errs]}
         del m
     res["note"] = ("same workload, same process; GEMM operands held as 3 (2) bf16 planes of the fp32 value, products on "
-                   "v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the two products of the attention included); LayerNorm / softmax / "
+                   "the bf16 MFMA (GEMMs: v_mfma_f32_16x16x32_bf16) with fp32 accumulation (the two products of the attention included); LayerNorm / softmax / "
                    "erf-GELU / residual fp32 as in the headline. Error vs the float64 oracle (tests/test_gpu_split_fp32.py, ViT-B): "
                    "f32x6 6.1-8.4e-7, headline fp32 MFMA build 7.2-9.3e-7, f32x3 4.4-5.6e-6")
     return res

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/{<tag>_bench.json, <tag>_kernel_stats.csv, pmc_<tag>_*} (scripts/prof_config.sh) into the tracked files
-under profiles/: <out>_bench.json, <out>_kernel_stats.csv, <out>_pmc_summary.txt, and one entry of profiles/r03_traffic.json
+under profiles/: <out>_bench.json, <out>_kernel_stats.csv, <out>_pmc_summary.txt, and one entry of profiles/r04_traffic.json
 (HBM bytes per GEMM launch + PMC MFMA utilisation, keyed by workload, labelled with the commit it was measured on) that
 bench.py reports as roofline.traffic.
 
@@ -72,7 +72,7 @@ for name, v in sq.items():
     short = name.replace("void ldit::(anonymous namespace)::", "").split("(")[0]
     per_kernel_util[short] = {"launches": len(v["SQ_VALU_MFMA_BUSY_CYCLES"]),
                               "mfma_util": sum(v["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(v["GRBM_GUI_ACTIVE"]) / 8.0 * 1024.0)}
-path = os.path.join(p, "r03_traffic.json")
+path = os.path.join(p, os.environ.get("TRAFFIC_JSON", "r04_traffic.json"))     # bench.py reads the newest one
 table = json.load(open(path)) if os.path.exists(path) else {}
 table[key] = {"commit": commit, "gemm_hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "launches_sampled": n,
               "gemm_mfma_util_pmc": util, "kernels": sorted(FAMILY), "per_kernel_mfma_util": per_kernel_util,

@@ -77,6 +77,7 @@ def test_rccl_control_plane_one_rank():
         "assert r.backend == 'nccl' and torch.distributed.is_initialized()\n"
         "dp.barrier(r)\n"
         "assert dp.max_over_ranks(r, 3.5) == 3.5 and dp.sum_over_ranks(r, 2.0) == 2.0\n"
+        "assert dp.gather_over_ranks(r, [1.5, 0.25, 7.0]) == [[1.5, 0.25, 7.0]]      # bench.py's per-rank report over RCCL\n"
         "g = torch.ones(1 << 20, device='cuda:0')\n"
         "torch.distributed.all_reduce(g)\n"
         "torch.cuda.synchronize(); assert float(g.sum()) == float(1 << 20)\n"
