@@ -476,30 +476,37 @@ int launch_h(const GemmArgsH &a, hipStream_t stream)
 // whole extra round of the machine; the round-1/2 answer was a split-K "skinny" kernel, whose eight K slices summed in another
 // order than a tile's k-loop, so the rows it served (the LAST image of a batch) depended on the batch layout - the strict
 // permutation test had to be relaxed for them - and it cost 11 - 38 us per call (9.6 % of the ViT-L step).  Here one wave owns
-// one 32 x 32 output tile and walks ALL of K in order, one v_mfma_f32_32x32x16_bf16 per 16-deep step into ONE accumulator with
-// the operands in the tile kernel's lane positions: per output element exactly the tile kernel's sequence of MFMAs, hence
-// its bits.  Fragments come straight from global memory (nothing is reused inside a wave; A is shared through L1 / L2 by
-// the N / 32 waves, W by nobody), sixteen 16-B loads per operand in flight per wave (two register sets of eight steps).
-// The epilogue is the tiles' direct store (store_h), spelled with the same fmas.
+// one output tile and walks ALL of K in order with the tile kernels' own MFMA, the operands in the tile kernels' lane positions,
+// into ONE accumulation chain per output element: per output element exactly the tile kernels' sequence of MFMAs, hence its bits.
+// Fragments come straight from global memory (nothing is reused inside a wave; A is shared through L1 / L2 by the waves of a row
+// block, W by nobody).  The epilogue is the tiles' direct store (store_h), spelled with the same fmas.
+// Round 4 (with the tile kernels): v_mfma_f32_16x16x32_bf16, a wave = 32 rows x 16 columns (two row sub-tiles; the second one is
+// skipped altogether when it lies past M - the peeled 16-row tail).  A load instruction now covers 16 rows x 64 contiguous bytes
+// (32 rows x 32 B before) and a 32-deep step costs two or three loads instead of four: the kernel is load-issue bound (~94 cycles per
+// pair of loads), so the per-wave chain - what its 6 - 17 us were made of - halves, and twice as many waves share the work.
 template <int EPI>
 __global__ void __launch_bounds__(64) gemm_bf16_tail(const GemmArgsH p)
 {
-    // A register set holds two GROUPS of four 16-deep steps; a group = one 64-deep k-tile of one plane segment (ordinary GEMM: one
-    // segment, so groups are the k-tiles in order - what this kernel always did).  Split-fp32 operands (GemmExtra::nseg): the groups
-    // are walked in the tile kernels' order (k-tile outermost when seg_inner, else segment outermost), so that a row gets the tile
-    // kernels' bits here too - which lets small batches of those builds run on this latency-oriented kernel.
-    constexpr int GPS = 2;                                // groups per register set (two sets: 16 steps = 32 KB in flight per wave)
-    const int lane = threadIdx.x, c32 = lane & 31, h = lane >> 5;
-    const int nct = (p.N + 31) / 32;
-    const int n0 = (blockIdx.x % nct) * 32, m0 = (blockIdx.x / nct) * 32;
-    const int ra = m0 + c32 < p.M ? m0 + c32 : p.M - 1, rw = n0 + c32 < p.N ? n0 + c32 : p.N - 1;
-    const bf16_t *ap = p.A + (size_t)ra * p.lda + 8 * h, *wp = p.W + (size_t)rw * p.ldw + 8 * h;
+    // A register set holds GPS GROUPS; a group = one 64-deep k-tile of one plane segment = two 32-deep steps (ordinary GEMM: one
+    // segment, so groups are the k-tiles in order).  Split-fp32 operands (GemmExtra::nseg): the groups are walked in the tile kernels'
+    // order (k-tile outermost when seg_inner, else segment outermost), so that a row gets the tile kernels' bits here too - which
+    // lets small batches of those builds run on this latency-oriented kernel.
+    constexpr int GPS = 4;                                // groups per register set (two sets: 16 steps of 32 in flight per wave)
+    const int lane = threadIdx.x, r16 = lane & 15, q16 = lane >> 4;
+    const int nct = (p.N + 15) / 16;
+    const int n0 = (blockIdx.x % nct) * 16, m0 = (blockIdx.x / nct) * 32;
+    const bool two = m0 + 16 < p.M;                       // block-uniform: the second 16-row sub-tile has a valid row
+    const int ra0 = m0 + r16 < p.M ? m0 + r16 : p.M - 1, ra1 = m0 + 16 + r16 < p.M ? m0 + 16 + r16 : p.M - 1;
+    const int rw = n0 + r16 < p.N ? n0 + r16 : p.N - 1;
+    const bf16_t *ap0 = p.A + (size_t)ra0 * p.lda + 8 * q16, *ap1 = p.A + (size_t)ra1 * p.lda + 8 * q16;
+    const bf16_t *wp = p.W + (size_t)rw * p.ldw + 8 * q16;
     const int nkb = p.K / BKB, nseg = p.x.nseg > 0 ? p.x.nseg : 1, ngroups = nkb * nseg;
-    f32x16 acc[1][1];
+    f32x4 acc[2][1];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.0f;
-    bf16x8 xa0[4 * GPS], wb0[4 * GPS], xa1[4 * GPS], wb1[4 * GPS];
-    auto ld = [&](bf16x8(&xa)[4 * GPS], bf16x8(&wb)[4 * GPS], int g0) {
+    for (int e = 0; e < 4; ++e) { acc[0][0][e] = 0.0f; acc[1][0][e] = 0.0f; }
+    struct Set { bf16x8 a0[2 * GPS], a1[2 * GPS], w[2 * GPS]; };
+    Set s0, s1;
+    auto ld = [&](Set &s, int g0) {
 #pragma unroll
         for (int gi = 0; gi < GPS; ++gi) {
             int G = g0 + gi < ngroups ? g0 + gi : ngroups - 1;            // clamped: a group past the end is loaded, never multiplied
@@ -511,35 +518,39 @@ __global__ void __launch_bounds__(64) gemm_bf16_tail(const GemmArgsH p)
             const unsigned ka = ((p.x.seg_a >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)kb * BKB;
             const unsigned kw = ((p.x.seg_w >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)kb * BKB;
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                xa[4 * gi + st] = *reinterpret_cast<const bf16x8 *>(ap + ka + 16 * st);
-                wb[4 * gi + st] = *reinterpret_cast<const bf16x8 *>(wp + kw + 16 * st);
+            for (int st = 0; st < 2; ++st) {
+                s.a0[2 * gi + st] = *reinterpret_cast<const bf16x8 *>(ap0 + ka + 32 * st);
+                if (two) s.a1[2 * gi + st] = *reinterpret_cast<const bf16x8 *>(ap1 + ka + 32 * st);
+                s.w[2 * gi + st] = *reinterpret_cast<const bf16x8 *>(wp + kw + 32 * st);
             }
         }
     };
-    auto mm = [&](const bf16x8(&xa)[4 * GPS], const bf16x8(&wb)[4 * GPS], int g0) {
+    auto mm = [&](const Set &s, int g0) {
 #pragma unroll
         for (int gi = 0; gi < GPS; ++gi)
             if (g0 + gi < ngroups)
 #pragma unroll
-                for (int st = 0; st < 4; ++st)
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[4 * gi + st], xa[4 * gi + st], acc[0][0], 0, 0, 0);
+                for (int st = 0; st < 2; ++st) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s.w[2 * gi + st], s.a0[2 * gi + st], acc[0][0], 0, 0, 0);
+                    if (two) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s.w[2 * gi + st], s.a1[2 * gi + st], acc[1][0], 0, 0, 0);
+                }
     };
-    ld(xa0, wb0, 0);
+    ld(s0, 0);
     for (int g0 = 0; g0 < ngroups; g0 += 2 * GPS) {
-        ld(xa1, wb1, g0 + GPS);
-        mm(xa0, wb0, g0);
-        ld(xa0, wb0, g0 + 2 * GPS);
-        mm(xa1, wb1, g0 + GPS);
+        ld(s1, g0 + GPS);
+        mm(s0, g0);
+        ld(s0, g0 + 2 * GPS);
+        mm(s1, g0 + GPS);
     }
-    if ((n0 + 32 <= p.N) && ((p.ldy & 3) == 0)) store_h<1, 1, EPI, 1>(p, acc, m0, n0, lane);
-    else store_h<1, 1, EPI, 2>(p, acc, m0, n0, lane);
+    // rows of a skipped second sub-tile are >= M: the row check of the direct store drops them
+    if ((n0 + 16 <= p.N) && ((p.ldy & 3) == 0)) store_h<1, 1, EPI, 1, true, 1>(p, acc, m0, n0, lane);
+    else store_h<1, 1, EPI, 2, true, 1>(p, acc, m0, n0, lane);
 }
 
 template <int EPI>
 int launch_tail(const GemmArgsH &a, hipStream_t stream)
 {
-    const unsigned blocks = (unsigned)(((a.N + 31) / 32) * ((a.M + 31) / 32));
+    const unsigned blocks = (unsigned)(((a.N + 15) / 16) * ((a.M + 31) / 32));
     hipLaunchKernelGGL(gemm_bf16_tail<EPI>, dim3(blocks), dim3(64), 0, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;

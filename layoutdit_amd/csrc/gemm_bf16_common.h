@@ -66,10 +66,13 @@ template <int EPI> constexpr bool f32_out() { return EPI == EPI_SCALE_RESID || E
 // L16: the accumulators are 2 TM x 2 TN tiles of 16 x 16 (v_mfma_f32_16x16x32_bf16: acc[i][j][e] = row 16 i + (lane & 15), column
 // 16 j + 4 (lane >> 4) + e): per 32 x 32 block a lane then owns two rows x two column quads instead of one row x four quads.  The
 // arithmetic per element is the same statement either way (same bits).
-template <int TM, int TN, int EPI, int MODE, bool L16 = false, typename ACC>
+// NQU (L16 only): column-quad groups of each 32-column block that exist in `acc` - 1 = the wave owns 16 columns per block, acc is
+// [2 TM][TN] (gemm_bf16_tail: one wave per 32 x 16 tile).
+template <int TM, int TN, int EPI, int MODE, bool L16 = false, int NQU = 0, typename ACC>
 __device__ __forceinline__ void store_h(const GemmArgsH &p, const ACC &acc, int mw, int nw, int lane)
 {
-    constexpr int NQ = L16 ? 2 : 4, NR = L16 ? 2 : 1;      // column quads per row, rows - per lane and 32 x 32 block
+    constexpr int NQ = NQU > 0 ? NQU : (L16 ? 2 : 4), NR = L16 ? 2 : 1;      // column quads per row, rows - per lane and 32 x 32 block
+    constexpr int JW = (L16 && NQU == 1) ? 1 : 2;           // 16-column accumulator tiles per 32-column block
     const int row_in = L16 ? (lane & 15) : (lane & 31), quad_in = L16 ? 4 * (lane >> 4) : 4 * (lane >> 5);
     constexpr int QSTEP = L16 ? 16 : 8;
     const bool dual = p.Y2 != nullptr;
@@ -112,7 +115,7 @@ __device__ __forceinline__ void store_h(const GemmArgsH &p, const ACC &acc, int 
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if constexpr (L16) v[e] = acc[2 * i + rr][2 * j + g][e] + bias[g][e];
+                    if constexpr (L16) v[e] = acc[2 * i + rr][JW * j + g][e] + bias[g][e];
                     else v[e] = acc[i][j][4 * g + e] + bias[g][e];
                 }
                 if (EPI == EPI_EMBED) {
