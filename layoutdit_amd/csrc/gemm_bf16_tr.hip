@@ -12,6 +12,11 @@
 // row is XOR-swizzled with (reduction row & 3) - on the DMA source address and on the read - so the four rows a group
 // touches fall on four different quarters of the 256-byte bank window (conflict-free; unswizzled they alias 4-way because
 // the row stride is a multiple of 256 bytes).
+// The matrix instruction is v_mfma_f32_32x32x16_bf16.  A v_mfma_f32_16x16x32_bf16 build of the main loop (-DLDIT_TR_MFMA16: the
+// shape that bought gemm_bf16.hip 2 % inside the models; same sums bit for bit; lane group q reads reduction rows 8 q .. 8 q + 7 of
+// a 32-deep step for one 16-column fragment, the two 32-byte halves of a granule swapped on rows with bit 3 set so the two groups
+// of a 32-lane half - rows 8 apart, same 16 columns - stay conflict-free) passes the same tests and measured 0.5 % SLOWER in the
+// train step on both tile sets (profiles/r04_tr_mfma16_ab.txt): kept for the A/B, not the default.
 // Reduction rows past the end (tokens are not a multiple of 64) are fetched from a page of zeros: LDS-DMA has no predication.
 //
 // Main loop (round 4: the pipeline of gemm_bf16.hip; rounds 2-3 ran a simple issue-all / read / multiply / barrier loop that left the
@@ -22,6 +27,7 @@
 // the issue stalls).  Same swapped-operand accumulator layout and epilogues as gemm_bf16.hip (fp32 / split-K slabs, bf16, dgrad x
 // saved GELU derivative, column sums).
 #include <cstdlib>
+#include <type_traits>
 
 #include "gemm_bf16_common.h"
 
@@ -40,12 +46,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A_BYTES = BM * ROWB, STAGE = (BM + BN) * ROWB;
     static_assert((!TA || BM == 128 || BM == 256) && (BN == 128 || BN == 256), "reduction-major images need 256- or 512-byte rows");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int c32 = lane & 31, h = lane >> 5;
 
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
     const int ntiles = nbm * nbn, nblocks = ntiles * p.x.splits;
@@ -93,33 +98,44 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
             const bool isA = 8 * piece < BM;
             const int BT = isA ? BM : BN, cpr = BT / 8, pa = isA ? piece : piece - BM / 8;
             const int kr = pa * (1024 / (BT * 2)) + lane / cpr, chunk = lane % cpr;
+#ifdef LDIT_TR_MFMA16
+            int col = (isA ? m0 : n0) + ((((chunk >> 2) ^ (kr & 3)) << 5) | (((chunk & 3) ^ ((kr >> 2) & 2)) << 3));
+#else
             int col = (isA ? m0 : n0) + ((((chunk >> 2) ^ (kr & 3)) << 5) | ((chunk & 3) << 3));
+#endif
             const int ncols = isA ? p.M : p.N;
             col = col + 8 <= ncols ? col : ncols - 8;         // columns past the matrix: duplicates, discarded by the epilogue
             src[u] = (unsigned)kr * (unsigned)(isA ? p.lda : p.ldw) + (unsigned)col;
         }
     }
+    // every k-tile but a ragged last one: the tile's advance travels in a scalar base, the lane's offset is the kernel constant src[u]
+    // (glds16h_sbase, gemm_bf16_common.h) - no vector address arithmetic per piece.  Pieces lo .. hi-1 of this wave's NLW.
+    // (k0 is scalar - kbeg was made so at its definition, far from here - so the bases are scalar-unit arithmetic on kernel-argument
+    // pointers: no v_readfirstlane result reaches the DMA's scalar base within its five wait states, cdna guide 5.7 item 2)
+    auto issue_sbase = [&](int stage, int k0, int lo, int hi) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)(smem + stage * STAGE)));
+        const bf16_t *a_k = p.A + (unsigned)k0, *a_r = p.A + (size_t)k0 * (size_t)p.lda, *w_r = p.W + (size_t)k0 * (size_t)p.ldw;
+#pragma unroll
+        for (int u = 0; u < NLW; ++u) {
+            if (u < lo || u >= hi) continue;
+            const int piece = piece_of(u);
+            const bool isA = 8 * piece < BM;
+            glds16h_sbase((!TA && isA) ? a_k : isA ? a_r : w_r, 2u * src[u], dst + piece * 1024);
+        }
+    };
+    // (the 320-row tile has no register left for the three scalar bases' set-up)
+#ifndef LDIT_BF16_VADDR_DMA
+    constexpr bool SBASE = TM < 5;
+#else
+    constexpr bool SBASE = false;
+#endif
     auto issue = [&](int stage, int k0) {                     // k0: first reduction index of the k-tile
         char *base = smem + stage * STAGE;
         const bool ragged = k0 + BKB > p.K;                   // block-uniform: only the last k-tile of the matrix
-#ifndef LDIT_BF16_VADDR_DMA
-        // (the 320-row tile has no register left for the three scalar bases' set-up: it would spill one VGPR)
-        if (TM < 5 && !ragged) {
-            // every k-tile but a ragged last one: the tile's advance travels in a scalar base, the lane's offset is the kernel
-            // constant src[u] (glds16h_sbase, gemm_bf16_common.h) - no vector address arithmetic per piece
-            const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)base));
-            // (k0 is scalar - kbeg was made so at its definition, far from here - so these are scalar-unit arithmetic on kernel-argument
-            // pointers: no v_readfirstlane result reaches the DMA's scalar base within its five wait states, cdna guide 5.7 item 2)
-            const bf16_t *a_k = p.A + (unsigned)k0, *a_r = p.A + (size_t)k0 * (size_t)p.lda, *w_r = p.W + (size_t)k0 * (size_t)p.ldw;
-#pragma unroll
-            for (int u = 0; u < NLW; ++u) {
-                const int piece = piece_of(u);
-                const bool isA = 8 * piece < BM;
-                glds16h_sbase((!TA && isA) ? a_k : isA ? a_r : w_r, 2u * src[u], dst + piece * 1024);
-            }
+        if (SBASE && !ragged) {
+            issue_sbase(stage, k0, 0, NLW);
             return;
         }
-#endif
 #pragma unroll
         for (int u = 0; u < NLW; ++u) {
             const int piece = piece_of(u);
@@ -136,6 +152,151 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
         }
     };
 
+#ifdef LDIT_TR_MFMA16
+    constexpr bool L16 = true;
+    // a 32 x 32 block of the wave tile = 2 x 2 accumulators of 16 x 16 (gemm_bf16.hip's arrangement: acc[row fragment][column fragment])
+    f32x4 acc[2 * TM][2 * TN];
+#pragma unroll
+    for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0f;
+
+    // ---- fragment addressing --------------------------------------------------------------------------------------------
+    // K-contiguous A (dgrad): as gemm_bf16.hip (one ds_read_b128 per 16-row fragment and 32-deep step).  Reduction-major image:
+    // lane (group q16 = lane >> 4, r16 = lane & 15) addresses reduction row 32 k32 + 8 q16 + 4 t + (r16 >> 2), columns
+    // cb + 4 (r16 & 3) .. + 3 of the fragment's 16 and receives column cb + r16 of reduction rows 32 k32 + 8 q16 + 4 t + 0..3 -
+    // the k = 8 q16 + 4 t .. + 3 elements the 16x16x32 operand wants in lane (r16, q16).
+    const int q16 = lane >> 4, r16 = lane & 15, swz = (r16 >> 2) & 3;
+    // One address register per operand: fragment f (16 columns) of the wave's column range lies at (base + step) ^ (f << 5) - the
+    // granule and half-granule swizzles are XORs of address bits 5 .. 5 + log2(fragments) and every other term (stage, 32-deep step,
+    // operand origin, row) is a multiple of 128 bytes or more, the LDS base included (aligned(128) below).
+    static_assert(!TA || TM == 2 || TM == 4, "XOR fragment addressing wants a power-of-two granule count per wave");
+    static_assert(TN == 2, "XOR fragment addressing wants a power-of-two granule count per wave");
+    unsigned ta0 = 0, a0 = 0, tw0;
+    {
+        constexpr int BPRA = BM * 2, BPRW = BN * 2;
+        const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)smem);
+        const int rowin = 8 * q16 + (r16 >> 2), inrow = 8 * (r16 & 3);
+        if (TA) ta0 = lds0 + rowin * BPRA + (((wm * TM) ^ swz) << 6) + ((q16 & 1) << 5) + inrow;
+        else a0 = lds0 + (wm * TM * 32 + r16) * ROWB + ((q16 ^ ((r16 >> 1) & 7)) << 4);      // K-contiguous rows: chunk (4 k32 + q16) ^ (row >> 1 & 7)
+        tw0 = lds0 + A_BYTES + rowin * BPRW + (((wn * TN) ^ swz) << 6) + ((q16 & 1) << 5) + inrow;
+    }
+    // two transposing reads: reduction rows 8 q16 + {0..3} and + {4..7} of the 32-deep step at `addr` (4 rows on = an immediate)
+    auto tr_frag = [&](unsigned addr, auto bpr4_c) -> bf16x8 {
+        union { s16x4 v[2]; bf16x8 f; } u;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u.v[0]) : "v"(addr));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u.v[1]) : "v"(addr), "n"(decltype(bpr4_c)::value));
+        return u.f;
+    };
+    // activation fragments of half `hf` (16-row fragments hf * TM .. hf * TM + TM - 1) of 32-deep step k32
+    auto load_a = [&](int stage, int k32, auto hf_c, bf16x8(&xa)[TM]) {
+        constexpr int hf = decltype(hf_c)::value;
+        if (TA) {
+            const unsigned so = (unsigned)(stage * STAGE + 32 * k32 * (BM * 2));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) xa[i] = tr_frag((ta0 + so) ^ (unsigned)((hf * TM + i) << 5), std::integral_constant<int, 4 * BM * 2>{});
+        } else {
+            // (asm like the transposing reads: hipcc would count these against the transposing reads it cannot see and wait for
+            //  freshly issued ones in front of this half step's MFMAs)
+            const unsigned addr = (a0 + (unsigned)(stage * STAGE)) ^ (unsigned)(k32 << 6);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[i]) : "v"(addr), "n"((hf * TM + i) * 16 * ROWB));
+        }
+    };
+    auto load_w = [&](int stage, int k32, bf16x8(&wb)[2 * TN]) {
+        const unsigned so = (unsigned)(stage * STAGE + 32 * k32 * (BN * 2));
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j) wb[j] = tr_frag((tw0 + so) ^ (unsigned)(j << 5), std::integral_constant<int, 4 * BN * 2>{});
+    };
+    auto mfma_half = [&](int hf, const bf16x8(&xa)[TM], const bf16x8(&wb)[2 * TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 * TN; ++j) {
+                if (hf == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+                else acc[TM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[TM + i][j], 0, 0, 0);
+            }
+    };
+
+    auto mfma_half1_dma = [&](const bf16x8(&xa)[TM], const bf16x8(&wb)[2 * TN], int stage, int k0) {
+        constexpr int NM = 2 * TM * TN, PPM = (NLW + NM - 1) / NM;
+#ifdef LDIT_TR_DEAL
+        const bool fast = SBASE && k0 + BKB <= p.K;
+#else
+        const bool fast = false;
+#endif
+        if (loader && !fast) issue(stage, k0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 * TN; ++j) {
+                acc[TM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[TM + i][j], 0, 0, 0);
+                if (loader && fast) issue_sbase(stage, k0, (i * 2 * TN + j) * PPM, (i * 2 * TN + j + 1) * PPM);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    bf16x8 xaA[TM], xaB[TM], wbX[2 * TN], wbY[2 * TN];
+    constexpr std::integral_constant<int, 0> H0{};
+    constexpr std::integral_constant<int, 1> H1{};
+    // k-tile kt of this block -> its first reduction index (past the end: the last tile again - fetched, never multiplied)
+    auto k_of = [&](int kt) { return kbeg + (kt < nk ? kt : nk - 1) * BKB; };
+    if (loader) {
+        issue(0, k_of(0));
+        issue(1, k_of(1));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tiles have landed before anybody reads them
+    __syncthreads();
+    load_a(0, 0, H0, xaA);
+    load_w(0, 0, wbX);
+    // Every LDS read of the loop is asm (hipcc would guard the builtin against the in-flight LDS-DMA with vmcnt(0), and would count
+    // its own ds_read_b128 against transposing reads it cannot see), so the order is pinned by hand, sched_barrier by sched_barrier:
+    // a half step ISSUES its reads, then its MFMAs (on the previous half step's fragments), then waits for the reads - left to the
+    // scheduler, the reads sank behind the MFMAs, right in front of the wait, and every half step exposed a full LDS latency.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // a 64-deep k-tile is four half steps (k32, half of the activation fragments): (0, a) (0, b) (1, a) (1, b), gemm_bf16.hip's order
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        // ---- (0, a): multiplies what the previous half step read, reads the activation fragments of (0, b)
+        load_a(cur, 0, H1, xaB);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(0, xaA, wbX);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- (0, b): reads all fragments of (1, a)
+        load_a(cur, 1, H0, xaA);
+        load_w(cur, 1, wbY);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(1, xaB, wbX);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- (1, a): reads the activation fragments of (1, b)
+        load_a(cur, 1, H1, xaB);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(0, xaA, wbY);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- hand-over: own DMA of tile kt+1 landed (vmcnt 0), own reads of stage cur done (lgkmcnt 0), then all waves
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- (1, b): the last fragments' MFMAs | first fragments of tile kt+1 | DMA of tile kt+2 -> stage cur (free now)
+        load_a(cur ^ 1, 0, H0, xaA);
+        load_w(cur ^ 1, 0, wbX);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half1_dma(xaB, wbY, cur, k_of(kt + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+#else
+    constexpr bool L16 = false;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -148,40 +309,48 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
     // K-contiguous A (dgrad): as gemm_bf16.hip.  Reduction-major image: lane (group g16 = lane>>4, i16 = lane&15) addresses
     // reduction row 16 s + 8 h + 4 t + (i16 >> 2), columns cb + 16 (g16 & 1) + 4 (i16 & 3) .. +3 and receives column
     // cb + (lane & 31) of reduction rows 16 s + 8 h + 4 t + 0..3.
+    const int c32 = lane & 31, h = lane >> 5;
     const int g16 = lane >> 4, i16 = lane & 15, swz = (i16 >> 2) & 3;
-    const int sw = (c32 >> 1) & 7;
-    const int a_row = (wm * TM * 32 + c32) * ROWB;
-    unsigned ta_addr[TM], tw_addr[TN];
+    unsigned ta_addr[TA ? TM : 1], tw_addr[TN], a0 = 0;
     {
         constexpr int BPRA = BM * 2, BPRW = BN * 2;
         const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)smem);
         const int inrow = (16 * (g16 & 1) + 4 * (i16 & 3)) * 2;
+        if (TA) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-            ta_addr[i] = lds0 + (8 * h + (i16 >> 2)) * BPRA + ((((wm * TM + i)) ^ swz) << 6) + inrow;
+            for (int i = 0; i < TM; ++i)
+                ta_addr[i] = lds0 + (8 * h + (i16 >> 2)) * BPRA + ((((wm * TM + i)) ^ swz) << 6) + inrow;
+        } else {
+            // K-contiguous rows: chunk (2 s + h) ^ (row >> 1 & 7) of row wm TM 32 + c32 (+ 32 i: an immediate); the step's
+            // "2 s" is an XOR of address bit 5 - every other term is a multiple of 128 bytes (aligned(128) above)
+            a0 = lds0 + (wm * TM * 32 + c32) * ROWB + ((h ^ ((c32 >> 1) & 7)) << 4);
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             tw_addr[j] = lds0 + A_BYTES + (8 * h + (i16 >> 2)) * BPRW + ((((wn * TN + j)) ^ swz) << 6) + inrow;
     }
-    auto tr_frag = [&](unsigned addr, int bpr, int s) -> bf16x8 {
+    // two transposing reads: reduction rows 16 s + 8 h + {0..3} and + {4..7} (both offsets are immediates)
+    auto tr_frag = [&](unsigned addr, auto off_c, auto bpr4_c) -> bf16x8 {
         union { s16x4 v[2]; bf16x8 f; } u;
-        // two transposing reads: reduction rows 16 s + 8 h + {0..3} and + {4..7}
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u.v[0]) : "v"(addr + (unsigned)((16 * s) * bpr)));
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u.v[1]) : "v"(addr + (unsigned)((16 * s + 4) * bpr)));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u.v[0]) : "v"(addr), "n"(decltype(off_c)::value));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u.v[1]) : "v"(addr), "n"(decltype(off_c)::value + decltype(bpr4_c)::value));
         return u.f;
     };
-    auto load_frags = [&](int stage, int s, bf16x8(&xa)[TM], bf16x8(&wb)[TN]) {
+    auto load_frags = [&](int stage, auto s_c, bf16x8(&xa)[TM], bf16x8(&wb)[TN]) {
+        constexpr int s = decltype(s_c)::value;
         const unsigned so = (unsigned)(stage * STAGE);
         if (TA) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) xa[i] = tr_frag(ta_addr[i] + so, BM * 2, s);
+            for (int i = 0; i < TM; ++i)
+                xa[i] = tr_frag(ta_addr[TA ? i : 0] + so, std::integral_constant<int, 16 * s * BM * 2>{}, std::integral_constant<int, 4 * BM * 2>{});
         } else {
-            const char *base = smem + stage * STAGE + ((s * 2 + h) ^ sw) * 16;
+            const unsigned addr = (a0 + so) ^ (unsigned)(s << 5);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const bf16x8 *>(base + a_row + i * 32 * ROWB);
+            for (int i = 0; i < TM; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[i]) : "v"(addr), "n"(i * 32 * ROWB));
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) wb[j] = tr_frag(tw_addr[j] + so, BN * 2, s);
+        for (int j = 0; j < TN; ++j)
+            wb[j] = tr_frag(tw_addr[j] + so, std::integral_constant<int, 16 * s * BN * 2>{}, std::integral_constant<int, 4 * BN * 2>{});
     };
     auto mfma_step = [&](const bf16x8(&xa)[TM], const bf16x8(&wb)[TN]) {
 #pragma unroll
@@ -191,6 +360,27 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
     };
 
+    // the hand-over step: a DMA-issuing wave's pieces of tile kt+2 go out in one burst in front of its MFMAs.  -DLDIT_TR_DEAL deals
+    // them between the MFMAs instead, pinned pair by pair (gemm_bf16.hip's arrangement): measured 0.7 % SLOWER in the train step on
+    // one box (profiles/r04_tr_pinned_order_ab.txt), kept for the A/B.  Either way the MFMAs stay outside every branch - an
+    // accumulator written on two paths costs the register allocator a copy of the tile (hundreds of spilled registers).
+    auto mfma_step_dma = [&](const bf16x8(&xa)[TM], const bf16x8(&wb)[TN], int stage, int k0) {
+        constexpr int NM = TM * TN, PPM = (NLW + NM - 1) / NM;
+#ifdef LDIT_TR_DEAL
+        const bool fast = SBASE && k0 + BKB <= p.K;           // block-uniform: every k-tile but a ragged last one
+#else
+        const bool fast = false;
+#endif
+        if (loader && !fast) issue(stage, k0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+                if (loader && fast) issue_sbase(stage, k0, (i * TN + j) * PPM, (i * TN + j + 1) * PPM);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
     bf16x8 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
     // k-tile kt of this block -> its first reduction index (past the end: the last tile again - fetched, never multiplied)
     auto k_of = [&](int kt) { return kbeg + (kt < nk ? kt : nk - 1) * BKB; };
@@ -200,36 +390,52 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tiles have landed before anybody reads them
     __syncthreads();
-    load_frags(0, 0, xa0, wb0);
-    // the transposing reads are asm (hipcc would guard the builtin against the in-flight LDS-DMA with vmcnt(0)): every group of
-    // reads is waited for by hand BEHIND the MFMAs issued after it, and the next step's MFMAs are pinned behind that wait
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+    constexpr std::integral_constant<int, 2> S2{};
+    constexpr std::integral_constant<int, 3> S3{};
+    load_frags(0, S0, xa0, wb0);
+    // Every LDS read of the loop is asm (hipcc would guard the transposing builtin against the in-flight LDS-DMA with vmcnt(0), and
+    // would count its own ds_read_b128 against transposing reads it cannot see), so the order is pinned by hand, sched_barrier by
+    // sched_barrier: a step ISSUES its reads, then its MFMAs (on the previous step's fragments), then waits for the reads.  Left to
+    // the scheduler (rounds 2 - 4a) the reads sank behind the MFMAs, right in front of the wait, and every step exposed a full LDS
+    // latency that only the SIMD partner covered.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        // ---- steps 0 .. 2: multiply the fragments read during the previous step, read the next ones
-        load_frags(cur, 1, xa1, wb1);
+        // ---- steps 0 .. 2: read the next step's fragments, multiply the ones read during the previous step
+        load_frags(cur, S1, xa1, wb1);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_step(xa0, wb0);
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        load_frags(cur, 2, xa0, wb0);
+        load_frags(cur, S2, xa0, wb0);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_step(xa1, wb1);
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        load_frags(cur, 3, xa1, wb1);
+        load_frags(cur, S3, xa1, wb1);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_step(xa0, wb0);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- hand-over: own DMA of tile kt+1 landed (vmcnt 0), own reads of stage cur done (lgkmcnt 0), then all waves
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        // ---- step 3: the last fragments' MFMAs | first fragments of tile kt+1 | DMA of tile kt+2 -> stage cur (free now)
-        load_frags(cur ^ 1, 0, xa0, wb0);
-        if (loader) issue(cur, k_of(kt + 2));
-        mfma_step(xa1, wb1);
+        // ---- step 3: first fragments of tile kt+1 | the last fragments' MFMAs | DMA of tile kt+2 -> stage cur (free now)
+        load_frags(cur ^ 1, S0, xa0, wb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step_dma(xa1, wb1, cur, k_of(kt + 2));
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
+
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-fetches of the tail must not outlive the LDS allocation
     __syncthreads();                                      // every wave is out of the k-loop: the stage memory becomes slab buffers
 
@@ -238,10 +444,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
     if (cols_in && (m0 + BM <= p.M || p.x.colsum)) {
         // (with column sums requested the ragged last row tile takes the slab path too, rows past M skipped)
         float *cs = (!f32_out<EPI>() && p.x.colsum) ? p.x.colsum + (size_t)((m0 / BM) * WM + wm) * (size_t)p.ldy : nullptr;
-        store_rows_via_lds<TM, TN, EPI, f32_out<EPI>() ? EPI_OUT_F32 : EPI_OUT_BF16>(
+        store_rows_via_lds<TM, TN, EPI, f32_out<EPI>() ? EPI_OUT_F32 : EPI_OUT_BF16, L16>(
             acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, nullptr, p.ldy, mw, nw, lane, 1.0f, 1.0f, p.x, p.M, cs);
-    } else if (cols_in) store_h<TM, TN, EPI, 1>(p, acc, mw, nw, lane);
-    else store_h<TM, TN, EPI, 2>(p, acc, mw, nw, lane);
+    } else if (cols_in) store_h<TM, TN, EPI, 1, L16>(p, acc, mw, nw, lane);
+    else store_h<TM, TN, EPI, 2, L16>(p, acc, mw, nw, lane);
 }
 
 template <int WM, int WN, int TM, int TN, int EPI, bool TA>
@@ -258,20 +464,35 @@ int launch_tr(const GemmArgsH &a, hipStream_t stream)
     return LDIT_OK;
 }
 
-template <int EPI, bool TA>
-int launch_tr_tiled(const GemmArgsH &a, hipStream_t stream)
+// The tile a launch takes for an [M, N] output with `splits` K-splits - the ONE place that decides (the launcher and the column-sum
+// row count below both ask here).  2: 128 x 128 (4 waves, two workgroups per CU), 3: 256 x 256 (8 waves) when that fills most of a
+// round, 6: 256 x 128 (wgrad form, forced only).  A K-contiguous A operand (dgrad) may also take the 192- / 320-row tiles (4 / 5)
+// of gemm_bf16.hip against round quantisation: whole rounds of 256 workgroups, priced as rounds x tile height.
+int tr_pick(long M, long N, int splits, bool ta)
 {
-    // 256 x 256 (8 waves) when that fills most of a round, else 128 x 128 (4 waves, two workgroups per CU).  A K-contiguous A
-    // operand (dgrad) may also take the 192- and 320-row tiles of gemm_bf16.hip against round quantisation: whole rounds of 256
-    // workgroups, priced as rounds x tile height.
-    const long o256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-    const long t256 = (long)a.x.splits * o256;
+    const long t256 = (long)splits * ((M + 255) / 256) * ((N + 255) / 256);
     int pick = t256 >= 120 ? 3 : 2;
-    (void)o256;
+#ifndef LDIT_TR_NO_TALL
+    if (!ta && pick == 3) {
+        double best = (double)((t256 + 255) / 256);
+        for (int bm : {192, 320}) {
+            const long t = (long)splits * ((M + bm - 1) / bm) * ((N + 255) / 256);
+            const double c = (double)((t + 255) / 256) * (bm / 256.0) * 1.03;
+            if (c < best) { best = c; pick = bm == 192 ? 4 : 5; }
+        }
+    }
+#endif
     // (wgrad form, round 4: a 256 x 128 eight-wave tile - one workgroup per CU, one DMA-issuing wave per SIMD - is selectable
     //  (LDIT_GEMM_BF16_TR_TILE=6).  Alone it beats the 128 x 128 tiles at the same split counts by 1 - 3 %; inside the train step it
     //  lost 5 % (75.6 vs ~70 us per call: profiles/r04_wgrad_tiles.txt), so two four-wave workgroups per CU stay the choice.)
-    if (const int force = diag().bf16_tr_tile; force >= 2 && (force <= (TA ? 3 : 5) || (TA && force == 6))) pick = force;
+    if (const int force = diag().bf16_tr_tile; force >= 2 && (force <= (ta ? 3 : 5) || (ta && force == 6))) pick = force;
+    return pick;
+}
+
+template <int EPI, bool TA>
+int launch_tr_tiled(const GemmArgsH &a, hipStream_t stream)
+{
+    const int pick = tr_pick(a.M, a.N, a.x.splits, TA);
     if constexpr (TA) {
         if (pick == 6) return launch_tr<4, 2, 2, 2, EPI, TA>(a, stream);     // 256 x 128, 4 x 2 waves of 64 x 64
     }
@@ -285,21 +506,12 @@ int launch_tr_tiled(const GemmArgsH &a, hipStream_t stream)
 
 }  // namespace
 
-// Partial rows a launch with GemmExtra::colsum writes for an M-row output (the tile height the launcher will pick for this shape
-// is a function of M, N alone): rows = row tiles x 2 wave rows; `bm` receives the tile height.
+// Partial rows a dgrad launch with GemmExtra::colsum writes for an M-row output: row tiles x 2 wave rows; `bm` receives the tile
+// height (tr_pick: the tile the launcher takes for this shape).
 int gemm_bf16_tr_colsum_rows(int M, int N, int *bm)
 {
-    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-    int h = t256 >= 120 ? 256 : 128;
-    if (h == 256) {
-        double best = (double)((t256 + 255) / 256);
-        for (int b : {192, 320}) {
-            const long t = (long)((M + b - 1) / b) * ((N + 255) / 256);
-            const double c = (double)((t + 255) / 256) * (b / 256.0) * 1.03;
-            if (c < best) { best = c; h = b; }
-        }
-    }
-    if (const int force = diag().bf16_tr_tile; force >= 2 && force <= 5) h = force == 2 ? 128 : force == 3 ? 256 : force == 4 ? 192 : 320;
+    const int pick = tr_pick(M, N, 1, false);
+    const int h = pick == 2 ? 128 : pick == 3 ? 256 : pick == 4 ? 192 : 320;
     if (bm) *bm = h;
     return ((M + h - 1) / h) * 2;
 }

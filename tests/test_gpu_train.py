@@ -323,6 +323,24 @@ def test_config2_full_size_train_step_vs_hf_golden_and_properties(golden_dir):
         e = rel_l2(got.reshape(-1)[::sample_stride(g, got.size)], g[f"eval_grad/{k}"])
         worst = max(worst, e)
         assert e < GRAD_TOL, (k, e, "bs=64 step vs HF golden of its first two images")
+    # -- 1b. the same two pages as the LAST two images of the batch (images reversed, upstream gradients on images 63, 62): every
+    #        reduction over tokens - weight gradients, bias column sums out of the GEMM epilogues, LayerNorm partial rows - must pick
+    #        up its last row tiles and partial rows as it does its first (round 4: the fc1 bias gradient once summed fewer partial
+    #        rows than the 256-row dgrad tiles had written; with gradients on images 0..1 only nothing noticed)
+    dt = []
+    for d in d2:
+        t = torch.zeros((B, N, Cc), device=DEV)
+        t[B - 2:] = torch.from_numpy(d).to(DEV).flip(0)
+        dt.append(t)
+    xr = x.flip(0).contiguous()
+    st.forward(xr, cfg.taps, None, saved)
+    st.backward(xr, cfg.taps, dt, None, saved, L, 0)
+    torch.cuda.synchronize()
+    for name, p, off, shape in st.named:
+        k = _hf_name(name)
+        got = st.grad_view(off, shape).cpu().numpy()
+        e = rel_l2(got.reshape(-1)[::sample_stride(g, got.size)], g[f"eval_grad/{k}"])
+        assert e < GRAD_TOL, (k, e, "bs=64 step, the golden's two pages as images 63, 62")
     # -- 2. batch invariance of the training forward
     saved2 = st.new_saved(2)
     taps2 = st.forward(x[:2].contiguous(), cfg.taps, None, saved2)
@@ -619,3 +637,43 @@ def test_wgrad_reads_both_operands_token_major(T, Nout, Kout, splits):
     if splits > 1:
         _lib.check(lib.ldit_reduce_slabs_f32(slabs.data_ptr(), out.data_ptr(), Nout * Kout, splits, _stream()))
     assert rel_l2(out.cpu().numpy(), (dy.double().T @ x.double()).numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("form,tiles", [("dgrad", (2, 3, 4, 5)), ("wgrad", (2, 3, 6))])
+def test_every_reduction_major_tile_gives_the_same_bits(form, tiles):
+    """Every tile of gemm_bf16_tr (128 x 128, 256 x 256, the 192- / 320-row dgrad tiles, the 256 x 128 wgrad tile) sums a dot product
+    in the same order: forcing each gives the default choice's output bit for bit, ragged row and column tiles included."""
+    lib = _lib.load()
+    zeros = torch.zeros(64, device=DEV)
+    outs = {}
+    try:
+        for tile in (None,) + tuple(tiles):
+            _lib.set_switch("LDIT_GEMM_BF16_TR_TILE", tile)
+            if form == "dgrad":
+                M, N, K = 1300, 520, 256
+                dy, w = _bf(_rand(80, M, K, scale=0.5)).to(DEV), _bf(_rand(81, K, N, scale=0.05)).to(DEV)
+                aux = _bf(_rand(82, M, N, scale=0.5) + 0.5).to(DEV)
+                got = []
+                for code, dt in ((_lib.EPI_F32, torch.float32), (_lib.EPI_BIAS, BF), (_lib.EPI_GELU_BWD, BF)):
+                    out = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+                    _lib.check(lib.ldit_linear_bf16_tr(dy.data_ptr(), K, 0, w.data_ptr(), N, out.data_ptr(), N, M, N, K, code,
+                                                       aux.data_ptr() if code == _lib.EPI_GELU_BWD else None, 1, zeros.data_ptr(), _stream()))
+                    got.append(out)
+                if tile is None:
+                    assert rel_l2(got[0].cpu().numpy(), (dy.double() @ w.double()).cpu().numpy()) < 1e-5
+            else:
+                T, Nout, Kout, splits = 1000, 264, 520, 2
+                dy, x = _bf(_rand(83, T, Nout, scale=0.3)).to(DEV), _bf(_rand(84, T, Kout, scale=0.3)).to(DEV)
+                slabs = torch.full((splits, Nout, Kout), float("nan"), device=DEV)
+                _lib.check(lib.ldit_linear_bf16_tr(dy.data_ptr(), Nout, 1, x.data_ptr(), Kout, slabs.data_ptr(), Kout, Nout, Kout, T,
+                                                   _lib.EPI_F32, None, splits, zeros.data_ptr(), _stream()))
+                got = [slabs]
+                if tile is None:
+                    assert rel_l2(slabs.sum(0).cpu().numpy(), (dy.double().T @ x.double()).cpu().numpy()) < 1e-5
+            torch.cuda.synchronize()
+            outs[tile] = got
+    finally:
+        _lib.set_switch("LDIT_GEMM_BF16_TR_TILE", None)
+    for tile in tiles:
+        for a, b in zip(outs[None], outs[tile]):
+            assert torch.equal(a, b), (form, tile)
