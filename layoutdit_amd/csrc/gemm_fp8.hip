@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_fp8_mfma(con
     constexpr int NWAVES = WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, ROWS = BM + BN, NLD = ROWS / (8 * NWAVES);
     static_assert(ROWS % (8 * NWAVES) == 0 && BM % 8 == 0, "DMA pieces must split evenly over the waves");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(128))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -218,39 +218,32 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_fp8_mfma(con
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tile has landed before anybody reads it
         __syncthreads();
         load_frags(0, 0, xa0, wb0);
+        // (round 4: the order reads | MFMAs is pinned with sched_barrier - left alone, the scheduler sinks a chunk's reads behind its
+        //  MFMAs, right in front of the wait that needs them: profiles/r04_tr_pinned_order_ab.txt, same finding as gemm_bf16_tr)
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             const int knext = (kt + 1 < nk ? kt + 1 : nk - 1) * BKE;
             load_frags(cur, 1, xa1, wb1);
+            __builtin_amdgcn_sched_barrier(0);
             issue(cur ^ 1, knext);
             mfma_chunk(xa0, wb0);
+            __builtin_amdgcn_sched_barrier(0);
             load_frags(cur, 2, xa0, wb0);
+            __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(xa1, wb1);
+            __builtin_amdgcn_sched_barrier(0);
             load_frags(cur, 3, xa1, wb1);
             __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(xa0, wb0);
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: do not rely on hipcc to drain the LDS-DMA in front of the barrier
             __syncthreads();   // hand-over: tile kt+1 landed in every wave, stage cur released
             load_frags(cur ^ 1, 0, xa0, wb0);
+            __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(xa1, wb1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
-        auto load_frags = [&](int stage, int c, i32x8(&xa)[TM], i32x8(&wb)[TN]) {
-            const char *base = smem + stage * (ROWS * ROW8);
-            const int o0 = ((4 * c + 2 * h) ^ sw) * 16, o1 = ((4 * c + 2 * h + 1) ^ sw) * 16;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const i32x4 lo = *reinterpret_cast<const i32x4 *>(base + a_row + i * 32 * ROW8 + o0);
-                const i32x4 hi = *reinterpret_cast<const i32x4 *>(base + a_row + i * 32 * ROW8 + o1);
-                xa[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const i32x4 lo = *reinterpret_cast<const i32x4 *>(base + b_row + j * 32 * ROW8 + o0);
-                const i32x4 hi = *reinterpret_cast<const i32x4 *>(base + b_row + j * 32 * ROW8 + o1);
-                wb[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
-        };
         auto mfma_chunk = [&](const i32x8(&xa)[TM], const i32x8(&wb)[TN]) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -263,23 +256,86 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_fp8_mfma(con
         // every wave's last fragments of tile kt are in registers) and waited for at the NEXT hand-over - a whole k-tile of MFMA
         // time (2048 cycles per SIMD) to land.  Rounds 1-2 issued tile kt+1 at the top of iteration kt and waited for it half a
         // k-tile later: shorter than an L2 / Infinity-Cache round trip under load, so every k-tile stalled on its own DMA.
+        // Round 4: the order reads | DMA pieces | MFMAs | wait is PINNED (sched_barrier), and for that every fragment read is an asm
+        // statement waited for by hand.  Left to hipcc, a chunk's reads sank behind its MFMAs - right in front of the wait that needs
+        // them, so the wait in front of the hand-over barrier and the first MFMA of the next chunk each sat out an LDS latency - and
+        // its own counted waits degenerated to lgkmcnt(0) right behind freshly issued reads (it cannot see across the asm DMA).
+        // The 320-row tile keeps hipcc's order: both fragment sets live at once (112 registers beside 160 of accumulators) do not
+        // fit, which is why the reads were sunk there in the first place.
+        constexpr bool PIN = TM < 5;
+        // fragment of rows r: chunks (4 c + 2 h) ^ sw and (4 c + 2 h + 1) ^ sw of the 128-byte row - the chunk index is an XOR of
+        // address bits 6 (c) and 4 (second half); every other term is a multiple of 128 bytes (aligned(128) stage memory)
+        const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)smem);
+        const unsigned fa0 = lds0 + a_row + (((2 * h) ^ sw) << 4), fb0 = lds0 + b_row + (((2 * h) ^ sw) << 4);
+        auto load_frags = [&](int stage, int c, i32x8(&xa)[TM], i32x8(&wb)[TN]) {
+            if constexpr (PIN) {
+                const unsigned so = (unsigned)(stage * (ROWS * ROW8));
+                const unsigned a_lo = (fa0 + so) ^ (unsigned)(c << 6), a_hi = a_lo ^ 16u, b_lo = (fb0 + so) ^ (unsigned)(c << 6), b_hi = b_lo ^ 16u;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    union { i32x4 v[2]; i32x8 f; } u;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(u.v[0]) : "v"(a_lo), "n"(i * 32 * ROW8));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(u.v[1]) : "v"(a_hi), "n"(i * 32 * ROW8));
+                    xa[i] = u.f;
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    union { i32x4 v[2]; i32x8 f; } u;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(u.v[0]) : "v"(b_lo), "n"(j * 32 * ROW8));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(u.v[1]) : "v"(b_hi), "n"(j * 32 * ROW8));
+                    wb[j] = u.f;
+                }
+            } else {
+                const char *base = smem + stage * (ROWS * ROW8);
+                const int o0 = ((4 * c + 2 * h) ^ sw) * 16, o1 = ((4 * c + 2 * h + 1) ^ sw) * 16;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const i32x4 lo = *reinterpret_cast<const i32x4 *>(base + a_row + i * 32 * ROW8 + o0);
+                    const i32x4 hi = *reinterpret_cast<const i32x4 *>(base + a_row + i * 32 * ROW8 + o1);
+                    xa[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const i32x4 lo = *reinterpret_cast<const i32x4 *>(base + b_row + j * 32 * ROW8 + o0);
+                    const i32x4 hi = *reinterpret_cast<const i32x4 *>(base + b_row + j * 32 * ROW8 + o1);
+                    wb[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            }
+        };
+        // (PIN: every group below is fenced; else the fences and hand waits for the reads drop out and hipcc orders / waits as before)
+        auto fence = [&]() { if constexpr (PIN) __builtin_amdgcn_sched_barrier(0); };
+        auto reads_done = [&]() { if constexpr (PIN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
         issue(0, 0);
         issue(1, (nk > 1 ? 1 : 0) * BKE);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");      // tile 0 landed; tile 1's NLD pieces stay in flight
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         load_frags(0, 0, xa0, wb0);
+        reads_done();
+        fence();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             const int k2 = (kt + 2 < nk ? kt + 2 : nk - 1) * BKE;
             load_frags(cur, 1, xa1, wb1);
+            fence();
             mfma_chunk(xa0, wb0);
+            fence();
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile kt+1 landed; own reads of stage cur retired
             __builtin_amdgcn_s_barrier();   // hand-over: tile kt+1 visible to every wave, stage cur released
             asm volatile("" ::: "memory");
-            issue(cur, k2);                 // tile kt+2 -> stage cur (a clamped re-fetch on the last two iterations, never read)
-            load_frags(cur ^ 1, 0, xa0, wb0);
+            fence();
+            if constexpr (PIN) {
+                load_frags(cur ^ 1, 0, xa0, wb0);
+                fence();
+                issue(cur, k2);             // tile kt+2 -> stage cur (a clamped re-fetch on the last two iterations, never read)
+            } else {
+                issue(cur, k2);
+                load_frags(cur ^ 1, 0, xa0, wb0);
+            }
             mfma_chunk(xa1, wb1);
+            fence();
+            reads_done();
+            fence();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-fetches must not outlive the LDS allocation
     }
