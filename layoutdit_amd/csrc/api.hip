@@ -70,7 +70,6 @@ DiagSwitches read_switches()
     d.seg_order = digit("LDIT_GEMM_SEG_ORDER", 0, 1);
     if (const char *e = getenv("LDIT_PLANES_TAIL_WAVES")) d.planes_tail_waves = atol(e);
     d.attn_bf16_nw = digit("LDIT_ATTN_BF16_NW", 4, 8);
-    d.train_side = is("LDIT_TRAIN_SIDE_STREAM", '1');
     return d;
 }
 DiagSwitches &switches()

@@ -18,7 +18,6 @@
 //                                          K = B*N tokens is split over workgroups, fp32 slabs summed in a fixed order
 // plus attention backward (attention_bwd_bf16.hip), LayerScale / LayerNorm backward with two-stage column reductions
 // (train_ops.hip).  Nothing uses atomics: gradients are bit-reproducible.
-#include <mutex>
 #include "api_internal.h"
 
 namespace ldit {
@@ -223,34 +222,6 @@ int forward_train(const ldit_cfg *cfg, const void *packed, const void *flat_para
     return LDIT_OK;
 }
 
-// Second queue for the weight-gradient GEMMs (LDIT_TRAIN_SIDE_STREAM=1, A/B): a wgrad has nothing downstream inside its layer but
-// the slab sum, so it can run beside the data-gradient chain - its long MFMA loop under the HBM-bound epilogues of the dgrad
-// GEMMs, LayerNorm and attention backward.  One stream + a ring of events per device, created on first use.
-struct SideQueue {
-    hipStream_t s = nullptr;
-    static constexpr int NEV = 64;
-    hipEvent_t ev[NEV] = {};
-    int next = 0;
-    bool ok = false;
-    hipEvent_t take() { hipEvent_t e = ev[next]; next = (next + 1) % NEV; return e; }
-};
-SideQueue *side_queue()
-{
-    static std::mutex mu;
-    static SideQueue q[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    SideQueue &sq = q[dev];
-    if (!sq.ok) {
-        if (hipStreamCreateWithFlags(&sq.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        for (int i = 0; i < SideQueue::NEV; ++i)
-            if (hipEventCreateWithFlags(&sq.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        sq.ok = true;
-    }
-    return &sq;
-}
-
 // one wgrad:  out[Nout, Kout] = dY[tokens, Nout]^T . X[tokens, Kout], both operands as they lie in memory; split-K slabs
 int wgrad(Probe &probe, ReduceJobs &jobs, const void *dY, int ld_dy, const void *X, int ld_x, float *out, float *slab, int Nout,
           int Kout, int tokens, const void *zeros, hipStream_t stream)
@@ -314,25 +285,6 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, c
     const int rows_tile = (int)wm.part_rows_tile, rows_ln = (int)wm.part_rows_ln;
     const int rows_lnr = C <= 1024 ? layernorm_bwd_resid_blocks((int64_t)M) : rows_ln;     // partial rows of the fused LayerNorm + LayerScale backward
     ReduceJobs jobs;
-    // (A/B) weight gradients on the side queue: `fork` makes it wait for everything enqueued on `stream` so far (the wgrad's operand
-    // is ready, the previous user of its slab has summed it), `join` makes `stream` wait for everything enqueued on the side
-    // (before an operand buffer the side still reads is overwritten, and before the slab sums).  Not while kernel families are timed.
-    SideQueue *sq = (diag().train_side && !probe.on) ? side_queue() : nullptr;
-    hipStream_t wstream = sq ? sq->s : stream;
-    auto fork = [&]() -> int {
-        if (!sq) return LDIT_OK;
-        hipEvent_t e = sq->take();
-        LDIT_HIP_CHECK(hipEventRecord(e, stream));
-        LDIT_HIP_CHECK(hipStreamWaitEvent(sq->s, e, 0));
-        return LDIT_OK;
-    };
-    auto join = [&]() -> int {
-        if (!sq) return LDIT_OK;
-        hipEvent_t e = sq->take();
-        LDIT_HIP_CHECK(hipEventRecord(e, sq->s));
-        LDIT_HIP_CHECK(hipStreamWaitEvent(stream, e, 0));
-        return LDIT_OK;
-    };
 
     if (stage_hi == g.L) LDIT_HIP_CHECK(hipMemsetAsync(dh, 0, act * 4, stream));
     for (int st = stage_hi; st >= stage_lo; --st) {
@@ -348,23 +300,19 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, c
 
         // ---- MLP branch:  h_out = h_mid + rs2 lam2 (.) (gelu(y2 W1^T + b1) W2^T + b2) --------------------------------
         LDIT_RUN(probe, LDIT_K_OTHER, launch_resid_bwd(dh, S + sl.z2, F32(pl.lam2), rs2, dz, nullptr, M, C, Mp, PART(0), PART(1), stream));
-        LDIT_TRY(fork());
-        LDIT_TRY(wgrad(probe, jobs, dz, C, S + sl.g, F, GR(gl.w2), reinterpret_cast<float *>(ws + wm.slab[0]), C, F, M, zeros, wstream));
+        LDIT_TRY(wgrad(probe, jobs, dz, C, S + sl.g, F, GR(gl.w2), reinterpret_cast<float *>(ws + wm.slab[0]), C, F, M, zeros, stream));
         // da1 = (dz W2) (.) gelu'; its column sums (the fc1 bias gradient) leave the same epilogue (F a multiple of 256), else a pass
         const bool b1_fused = F % 256 == 0;
         LDIT_TRY(dgrad(probe, dz, C, W16 + gl.w2 / 2, da1, M, F, EPI_GELU_BWD, S + sl.a1, zeros, stream, b1_fused ? PART(2) : nullptr));
         if (!b1_fused) LDIT_RUN(probe, LDIT_K_OTHER, launch_colsum_bf16(da1, M, F, F, PART(2), stream));
-        LDIT_TRY(fork());
-        LDIT_TRY(wgrad(probe, jobs, da1, F, S + sl.y2, C, GR(gl.w1), reinterpret_cast<float *>(ws + wm.slab[1]), F, C, M, zeros, wstream));
+        LDIT_TRY(wgrad(probe, jobs, da1, F, S + sl.y2, C, GR(gl.w1), reinterpret_cast<float *>(ws + wm.slab[1]), F, C, M, zeros, stream));
         LDIT_TRY(dgrad(probe, da1, F, W16 + gl.w1 / 2, dy, M, C, EPI_F32, nullptr, zeros, stream));
         // ---- attention branch:  h_mid = h_in + rs1 lam1 (.) (attn(LN1(h_in)) Wo^T + bo) --------------------------------
         // its LayerScale / residual backward rides in the LayerNorm backward that produces dh (h_mid): one pass, dh read once
-        LDIT_TRY(join());           // dz is rewritten below: the side's wgrad of W2 has read it
         LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bwd_resid(dy, reinterpret_cast<const float *>(S + sl.h_mid), F32(pl.ln2_w), dh, M, C,
                                                                     cfg->ln_eps, PART(3), PART(4), S + sl.z1, F32(pl.lam1), rs1, dz, PART(5),
                                                                     PART(6), stream));
-        LDIT_TRY(fork());
-        LDIT_TRY(wgrad(probe, jobs, dz, C, S + sl.o, C, GR(gl.wo), reinterpret_cast<float *>(ws + wm.slab[2]), C, C, M, zeros, wstream));
+        LDIT_TRY(wgrad(probe, jobs, dz, C, S + sl.o, C, GR(gl.wo), reinterpret_cast<float *>(ws + wm.slab[2]), C, C, M, zeros, stream));
         LDIT_TRY(dgrad(probe, dz, C, W16 + gl.wo / 2, dob, M, C, EPI_BIAS, nullptr, zeros, stream));
         {
             const char *qkv = S + sl.qkv;
@@ -374,13 +322,11 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, c
                                                dqkv + 4 * (size_t)C, batch, g.T, g.H, g.D, 3 * C, C, C, 3 * C, scale, stream));
         }
         LDIT_RUN(probe, LDIT_K_OTHER, launch_colsum_bf16(dqkv, M, 3 * C, 3 * C, PART(7), stream));
-        LDIT_TRY(fork());
-        LDIT_TRY(wgrad(probe, jobs, dqkv, 3 * C, S + sl.y1, C, GR(gl.wqkv), reinterpret_cast<float *>(ws + wm.slab[3]), 3 * C, C, M, zeros, wstream));
+        LDIT_TRY(wgrad(probe, jobs, dqkv, 3 * C, S + sl.y1, C, GR(gl.wqkv), reinterpret_cast<float *>(ws + wm.slab[3]), 3 * C, C, M, zeros, stream));
         LDIT_TRY(dgrad(probe, dqkv, 3 * C, W16 + gl.wqkv / 2, dy, M, C, EPI_F32, nullptr, zeros, stream));
         LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bwd(dy, reinterpret_cast<const float *>(S + sl.h_in), F32(pl.ln1_w), dh, M, C,
                                                               cfg->ln_eps, PART(8), PART(9), stream));
         // ---- second stage of this layer's reductions: 4 wgrad slab sums (queued above) + 10 vectors, one launch ----------
-        LDIT_TRY(join());           // the slabs are complete (and dz / da1 / dqkv free for the next layer)
         if (jobs.n + 10 > 16) LDIT_RUN(probe, LDIT_K_OTHER, launch_reduce_jobs(jobs, stream));
         jobs.add(PART(0), GR(gl.lam2), C, rows_tile, C);
         jobs.add(PART(1), GR(gl.b2), C, rows_tile, C);

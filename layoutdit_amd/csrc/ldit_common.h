@@ -60,7 +60,6 @@ struct DiagSwitches {
     bool attn_bf16_kt4 = false;  // LDIT_ATTN_BF16_KT=4
     int attn_bf16_nw = -1;       // LDIT_ATTN_BF16_NW=8: eight query tiles per workgroup (one staging of a chunk per 256 queries)
     long planes_tail_waves = 700;    // LDIT_PLANES_TAIL_WAVES: split-fp32 GEMMs of at most this many 32 x 32 output tiles run on the one-wave-per-tile kernel
-    bool train_side = false;     // LDIT_TRAIN_SIDE_STREAM=1: the backward's weight-gradient GEMMs on a second queue beside the data-gradient chain (A/B)
     int seg_order = -1;          // LDIT_GEMM_SEG_ORDER 0 = plane segments outermost (whole K per segment), 1 = innermost (per k-tile)
 };
 const DiagSwitches &diag();
