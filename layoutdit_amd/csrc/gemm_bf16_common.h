@@ -35,6 +35,19 @@ __device__ __forceinline__ void glds16h_sbase(const void *ubase, unsigned voff_b
                  : "memory");
 }
 
+// The same piece from a per-lane 64-bit address (ragged tiles, zero-page redirects), also as an asm statement: a kernel whose every
+// LDS-DMA is invisible to hipcc keeps its LDS reads free of the vmcnt(0) guards hipcc puts in front of reads that may alias a
+// builtin LDS-DMA in flight.  `lds_dst` must be wave-uniform (it travels in M0).
+__device__ __forceinline__ void glds16h_vaddr(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+
 // a wave-uniform pointer that hipcc computed on the vector unit (integer divisions, 64-bit multiplies) -> scalar registers
 template <typename T>
 __device__ __forceinline__ const T *uniform_ptr(const T *q)

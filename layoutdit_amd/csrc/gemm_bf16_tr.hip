@@ -98,11 +98,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
             const bool isA = 8 * piece < BM;
             const int BT = isA ? BM : BN, cpr = BT / 8, pa = isA ? piece : piece - BM / 8;
             const int kr = pa * (1024 / (BT * 2)) + lane / cpr, chunk = lane % cpr;
-#ifdef LDIT_TR_MFMA16
-            int col = (isA ? m0 : n0) + ((((chunk >> 2) ^ (kr & 3)) << 5) | (((chunk & 3) ^ ((kr >> 2) & 2)) << 3));
-#else
             int col = (isA ? m0 : n0) + ((((chunk >> 2) ^ (kr & 3)) << 5) | ((chunk & 3) << 3));
-#endif
             const int ncols = isA ? p.M : p.N;
             col = col + 8 <= ncols ? col : ncols - 8;         // columns past the matrix: duplicates, discarded by the epilogue
             src[u] = (unsigned)kr * (unsigned)(isA ? p.lda : p.ldw) + (unsigned)col;
@@ -148,154 +144,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
                 g = opnd + ((size_t)k0 * (size_t)(isA ? p.lda : p.ldw) + src[u]);
                 if (ragged && k0 + krow_of(u) >= p.K) g = static_cast<const bf16_t *>(p.x.zeros) + 8 * (lane & 7);
             }
-            glds16h(g, base + piece * 1024);
+            glds16h_vaddr(g, (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)(base + piece * 1024)));
         }
     };
 
-#ifdef LDIT_TR_MFMA16
-    constexpr bool L16 = true;
-    // a 32 x 32 block of the wave tile = 2 x 2 accumulators of 16 x 16 (gemm_bf16.hip's arrangement: acc[row fragment][column fragment])
-    f32x4 acc[2 * TM][2 * TN];
-#pragma unroll
-    for (int i = 0; i < 2 * TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 2 * TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0f;
-
-    // ---- fragment addressing --------------------------------------------------------------------------------------------
-    // K-contiguous A (dgrad): as gemm_bf16.hip (one ds_read_b128 per 16-row fragment and 32-deep step).  Reduction-major image:
-    // lane (group q16 = lane >> 4, r16 = lane & 15) addresses reduction row 32 k32 + 8 q16 + 4 t + (r16 >> 2), columns
-    // cb + 4 (r16 & 3) .. + 3 of the fragment's 16 and receives column cb + r16 of reduction rows 32 k32 + 8 q16 + 4 t + 0..3 -
-    // the k = 8 q16 + 4 t .. + 3 elements the 16x16x32 operand wants in lane (r16, q16).
-    const int q16 = lane >> 4, r16 = lane & 15, swz = (r16 >> 2) & 3;
-    // One address register per operand: fragment f (16 columns) of the wave's column range lies at (base + step) ^ (f << 5) - the
-    // granule and half-granule swizzles are XORs of address bits 5 .. 5 + log2(fragments) and every other term (stage, 32-deep step,
-    // operand origin, row) is a multiple of 128 bytes or more, the LDS base included (aligned(128) below).
-    static_assert(!TA || TM == 2 || TM == 4, "XOR fragment addressing wants a power-of-two granule count per wave");
-    static_assert(TN == 2, "XOR fragment addressing wants a power-of-two granule count per wave");
-    unsigned ta0 = 0, a0 = 0, tw0;
-    {
-        constexpr int BPRA = BM * 2, BPRW = BN * 2;
-        const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char *)smem);
-        const int rowin = 8 * q16 + (r16 >> 2), inrow = 8 * (r16 & 3);
-        if (TA) ta0 = lds0 + rowin * BPRA + (((wm * TM) ^ swz) << 6) + ((q16 & 1) << 5) + inrow;
-        else a0 = lds0 + (wm * TM * 32 + r16) * ROWB + ((q16 ^ ((r16 >> 1) & 7)) << 4);      // K-contiguous rows: chunk (4 k32 + q16) ^ (row >> 1 & 7)
-        tw0 = lds0 + A_BYTES + rowin * BPRW + (((wn * TN) ^ swz) << 6) + ((q16 & 1) << 5) + inrow;
-    }
-    // two transposing reads: reduction rows 8 q16 + {0..3} and + {4..7} of the 32-deep step at `addr` (4 rows on = an immediate)
-    auto tr_frag = [&](unsigned addr, auto bpr4_c) -> bf16x8 {
-        union { s16x4 v[2]; bf16x8 f; } u;
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u.v[0]) : "v"(addr));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u.v[1]) : "v"(addr), "n"(decltype(bpr4_c)::value));
-        return u.f;
-    };
-    // activation fragments of half `hf` (16-row fragments hf * TM .. hf * TM + TM - 1) of 32-deep step k32
-    auto load_a = [&](int stage, int k32, auto hf_c, bf16x8(&xa)[TM]) {
-        constexpr int hf = decltype(hf_c)::value;
-        if (TA) {
-            const unsigned so = (unsigned)(stage * STAGE + 32 * k32 * (BM * 2));
-#pragma unroll
-            for (int i = 0; i < TM; ++i) xa[i] = tr_frag((ta0 + so) ^ (unsigned)((hf * TM + i) << 5), std::integral_constant<int, 4 * BM * 2>{});
-        } else {
-            // (asm like the transposing reads: hipcc would count these against the transposing reads it cannot see and wait for
-            //  freshly issued ones in front of this half step's MFMAs)
-            const unsigned addr = (a0 + (unsigned)(stage * STAGE)) ^ (unsigned)(k32 << 6);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[i]) : "v"(addr), "n"((hf * TM + i) * 16 * ROWB));
-        }
-    };
-    auto load_w = [&](int stage, int k32, bf16x8(&wb)[2 * TN]) {
-        const unsigned so = (unsigned)(stage * STAGE + 32 * k32 * (BN * 2));
-#pragma unroll
-        for (int j = 0; j < 2 * TN; ++j) wb[j] = tr_frag((tw0 + so) ^ (unsigned)(j << 5), std::integral_constant<int, 4 * BN * 2>{});
-    };
-    auto mfma_half = [&](int hf, const bf16x8(&xa)[TM], const bf16x8(&wb)[2 * TN]) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < 2 * TN; ++j) {
-                if (hf == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
-                else acc[TM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[TM + i][j], 0, 0, 0);
-            }
-    };
-
-    auto mfma_half1_dma = [&](const bf16x8(&xa)[TM], const bf16x8(&wb)[2 * TN], int stage, int k0) {
-        constexpr int NM = 2 * TM * TN, PPM = (NLW + NM - 1) / NM;
-#ifdef LDIT_TR_DEAL
-        const bool fast = SBASE && k0 + BKB <= p.K;
-#else
-        const bool fast = false;
-#endif
-        if (loader && !fast) issue(stage, k0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < 2 * TN; ++j) {
-                acc[TM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[TM + i][j], 0, 0, 0);
-                if (loader && fast) issue_sbase(stage, k0, (i * 2 * TN + j) * PPM, (i * 2 * TN + j + 1) * PPM);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-    };
-    bf16x8 xaA[TM], xaB[TM], wbX[2 * TN], wbY[2 * TN];
-    constexpr std::integral_constant<int, 0> H0{};
-    constexpr std::integral_constant<int, 1> H1{};
-    // k-tile kt of this block -> its first reduction index (past the end: the last tile again - fetched, never multiplied)
-    auto k_of = [&](int kt) { return kbeg + (kt < nk ? kt : nk - 1) * BKB; };
-    if (loader) {
-        issue(0, k_of(0));
-        issue(1, k_of(1));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tiles have landed before anybody reads them
-    __syncthreads();
-    load_a(0, 0, H0, xaA);
-    load_w(0, 0, wbX);
-    // Every LDS read of the loop is asm (hipcc would guard the builtin against the in-flight LDS-DMA with vmcnt(0), and would count
-    // its own ds_read_b128 against transposing reads it cannot see), so the order is pinned by hand, sched_barrier by sched_barrier:
-    // a half step ISSUES its reads, then its MFMAs (on the previous half step's fragments), then waits for the reads - left to the
-    // scheduler, the reads sank behind the MFMAs, right in front of the wait, and every half step exposed a full LDS latency.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    // a 64-deep k-tile is four half steps (k32, half of the activation fragments): (0, a) (0, b) (1, a) (1, b), gemm_bf16.hip's order
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        // ---- (0, a): multiplies what the previous half step read, reads the activation fragments of (0, b)
-        load_a(cur, 0, H1, xaB);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_half(0, xaA, wbX);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- (0, b): reads all fragments of (1, a)
-        load_a(cur, 1, H0, xaA);
-        load_w(cur, 1, wbY);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_half(1, xaB, wbX);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- (1, a): reads the activation fragments of (1, b)
-        load_a(cur, 1, H1, xaB);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_half(0, xaA, wbY);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- hand-over: own DMA of tile kt+1 landed (vmcnt 0), own reads of stage cur done (lgkmcnt 0), then all waves
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- (1, b): the last fragments' MFMAs | first fragments of tile kt+1 | DMA of tile kt+2 -> stage cur (free now)
-        load_a(cur ^ 1, 0, H0, xaA);
-        load_w(cur ^ 1, 0, wbX);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_half1_dma(xaB, wbY, cur, k_of(kt + 2));
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-#else
     constexpr bool L16 = false;
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -329,6 +181,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
         for (int j = 0; j < TN; ++j)
             tw_addr[j] = lds0 + A_BYTES + (8 * h + (i16 >> 2)) * BPRW + ((((wn * TN + j)) ^ swz) << 6) + inrow;
     }
+#ifndef LDIT_TR_DEALT_READS
     // two transposing reads: reduction rows 16 s + 8 h + {0..3} and + {4..7} (both offsets are immediates)
     auto tr_frag = [&](unsigned addr, auto off_c, auto bpr4_c) -> bf16x8 {
         union { s16x4 v[2]; bf16x8 f; } u;
@@ -336,21 +189,47 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(u.v[1]) : "v"(addr), "n"(decltype(off_c)::value + decltype(bpr4_c)::value));
         return u.f;
     };
+#else
+    // (every LDS-DMA of this kernel is an asm statement, so hipcc sees plain LDS reads here: no vmcnt guard, its own counted lgkmcnt)
+    auto tr_frag = [&](unsigned addr, auto off_c, auto bpr4_c) -> bf16x8 {
+        union { s16x4 v[2]; bf16x8 f; } u;
+        typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+        u.v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(addr + (unsigned)decltype(off_c)::value));
+        u.v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(uintptr_t)(addr + (unsigned)(decltype(off_c)::value + decltype(bpr4_c)::value)));
+        return u.f;
+    };
+#endif
+    // (issued in the order the next step's MFMAs need them - wb[0], xa[0], wb[1], xa[1], xa[2] ... for MFMAs (0,0) (0,1) (1,0) ... -
+    //  so the first MFMA behind a step boundary waits for the OLDEST reads of the previous step)
     auto load_frags = [&](int stage, auto s_c, bf16x8(&xa)[TM], bf16x8(&wb)[TN]) {
         constexpr int s = decltype(s_c)::value;
         const unsigned so = (unsigned)(stage * STAGE);
-        if (TA) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                xa[i] = tr_frag(ta_addr[TA ? i : 0] + so, std::integral_constant<int, 16 * s * BM * 2>{}, std::integral_constant<int, 4 * BM * 2>{});
-        } else {
-            const unsigned addr = (a0 + so) ^ (unsigned)(s << 5);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[i]) : "v"(addr), "n"(i * 32 * ROWB));
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            wb[j] = tr_frag(tw_addr[j] + so, std::integral_constant<int, 16 * s * BN * 2>{}, std::integral_constant<int, 4 * BN * 2>{});
+        const unsigned addr = (a0 + so) ^ (unsigned)(s << 5);
+        auto read_a = [&](int, auto i_c) {
+            constexpr int I = decltype(i_c)::value;
+            if (TA) {
+                xa[I] = tr_frag(ta_addr[TA ? I : 0] + so, std::integral_constant<int, 16 * s * BM * 2>{}, std::integral_constant<int, 4 * BM * 2>{});
+            } else {
+#ifndef LDIT_TR_DEALT_READS
+                const unsigned ad = addr;       // (an asm operand alone does not capture a variable of the enclosing lambda)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[I]) : "v"(ad), "n"(I * 32 * ROWB));
+#else
+                xa[I] = *(const __attribute__((address_space(3))) bf16x8 *)(uintptr_t)(addr + (unsigned)(I * 32 * ROWB));
+#endif
+            }
+        };
+        auto read_w = [&](auto j_c) {
+            constexpr int J = decltype(j_c)::value;
+            wb[J] = tr_frag(tw_addr[J] + so, std::integral_constant<int, 16 * s * BN * 2>{}, std::integral_constant<int, 4 * BN * 2>{});
+        };
+        static_assert(TN == 2 && TM >= 2 && TM <= 5, "read order written out for two column fragments");
+        read_w(std::integral_constant<int, 0>{});
+        read_a(0, std::integral_constant<int, 0>{});
+        read_w(std::integral_constant<int, 1>{});
+        read_a(1, std::integral_constant<int, 1>{});
+        if constexpr (TM > 2) read_a(2, std::integral_constant<int, 2>{});
+        if constexpr (TM > 3) read_a(3, std::integral_constant<int, 3>{});
+        if constexpr (TM > 4) read_a(4, std::integral_constant<int, 4>{});
     };
     auto mfma_step = [&](const bf16x8(&xa)[TM], const bf16x8(&wb)[TN]) {
 #pragma unroll
@@ -360,6 +239,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
     };
 
+#ifndef LDIT_TR_DEALT_READS
     // the hand-over step: a DMA-issuing wave's pieces of tile kt+2 go out in one burst in front of its MFMAs.  -DLDIT_TR_DEAL deals
     // them between the MFMAs instead, pinned pair by pair (gemm_bf16.hip's arrangement): measured 0.7 % SLOWER in the train step on
     // one box (profiles/r04_tr_pinned_order_ab.txt), kept for the A/B.  Either way the MFMAs stay outside every branch - an
@@ -381,6 +261,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
+#endif
     bf16x8 xa0[TM], wb0[TN], xa1[TM], wb1[TN];
     // k-tile kt of this block -> its first reduction index (past the end: the last tile again - fetched, never multiplied)
     auto k_of = [&](int kt) { return kbeg + (kt < nk ? kt : nk - 1) * BKB; };
@@ -395,6 +276,62 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
     constexpr std::integral_constant<int, 2> S2{};
     constexpr std::integral_constant<int, 3> S3{};
     load_frags(0, S0, xa0, wb0);
+#ifdef LDIT_TR_DEALT_READS
+    // Pinned pipeline, gemm_bf16.hip's: a step multiplies the fragments read during the previous step while the next step's are
+    // read - the LDS reads DEALT between the step's first MFMAs (sched_group_barrier), hipcc's own counted lgkmcnt in front of each
+    // MFMA that needs a fragment (it can count: every read is its own instruction, every LDS-DMA is asm and invisible to it).
+    // Rounds 2 - 4a had the transposing reads as asm statements with hand waits: the scheduler sank them behind the MFMAs, right in
+    // front of the wait (profiles/r04_tr_pinned_order_ab.txt); round 4b pinned reads | MFMAs | wait with sched_barrier - the burst
+    // of reads in front of every step's MFMAs (both waves of a SIMD leave the hand-over barrier together) left the k-loop 17 % slower
+    // per k than the forward GEMM's (scripts/tr_fit.py).  THIS build (-DLDIT_TR_DEALT_READS) closes that gap alone - dgrad 70 -> 62e-3
+    // us per k on the 320-row tile, 17.4 -> 16.0e-3 on N = 768 - and LOSES 0.7 - 0.8 % inside the train step on two boxes
+    // (profiles/r04_tr_pinned_order_ab.txt): the burst build stays the default, this one is kept for the A/B.
+    constexpr int SG_MFMA = 0x8, SG_DSR = 0x100;
+    // MFMAs and LDS reads per step; the reads are dealt over the FIRST HALF of the step's MFMAs (the second half covers the latency
+    // of the last ones: the next step's first MFMA needs fragments from the middle of the read order)
+#ifndef LDIT_TR_DEAL_SPAN
+#define LDIT_TR_DEAL_SPAN 2
+#endif
+    constexpr int NM = TM * TN, NR = (TA ? 2 * TM : TM) + 2 * TN, NMD = NM / LDIT_TR_DEAL_SPAN > 0 ? NM / LDIT_TR_DEAL_SPAN : 1, RPM = (NR + NMD - 1) / NMD;
+    auto deal = [&](auto id_c) {
+        constexpr int ID = decltype(id_c)::value;
+#pragma unroll
+        for (int g = 0; g < NM; ++g) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, ID);
+#pragma unroll
+            for (int r = 0; r < RPM; ++r)
+                if (g * RPM + r < NR) __builtin_amdgcn_sched_group_barrier(SG_DSR, 1, ID);
+        }
+    };
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(cur, S1, xa1, wb1);
+        mfma_step(xa0, wb0);
+        deal(S0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(cur, S2, xa0, wb0);
+        mfma_step(xa1, wb1);
+        deal(S1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(cur, S3, xa1, wb1);
+        mfma_step(xa0, wb0);
+        deal(S2);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- hand-over: own DMA of tile kt+1 landed (vmcnt 0: the pieces are asm, hipcc does not wait for them), own reads of
+        //      stage cur done (hipcc's lgkmcnt in front of the barrier), then all waves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- step 3: first fragments of tile kt+1 | the last fragments' MFMAs | DMA of tile kt+2 -> stage cur (free now)
+        //      (the pieces are asm statements with a memory clobber - no LDS read moves across them - so they follow the step's MFMAs
+        //       and reads in program order and go out while the MFMAs drain; they still have three steps to land)
+        load_frags(cur ^ 1, S0, xa0, wb0);
+        mfma_step(xa1, wb1);
+        deal(S3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (loader) issue(cur, k_of(kt + 2));
+    }
+#else
     // Every LDS read of the loop is asm (hipcc would guard the transposing builtin against the in-flight LDS-DMA with vmcnt(0), and
     // would count its own ds_read_b128 against transposing reads it cannot see), so the order is pinned by hand, sched_barrier by
     // sched_barrier: a step ISSUES its reads, then its MFMAs (on the previous step's fragments), then waits for the reads.  Left to
