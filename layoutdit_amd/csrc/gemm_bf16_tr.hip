@@ -12,18 +12,18 @@
 // row is XOR-swizzled with (reduction row & 3) - on the DMA source address and on the read - so the four rows a group
 // touches fall on four different quarters of the 256-byte bank window (conflict-free; unswizzled they alias 4-way because
 // the row stride is a multiple of 256 bytes).
-// The matrix instruction is v_mfma_f32_32x32x16_bf16.  A v_mfma_f32_16x16x32_bf16 build of the main loop (-DLDIT_TR_MFMA16: the
-// shape that bought gemm_bf16.hip 2 % inside the models; same sums bit for bit; lane group q reads reduction rows 8 q .. 8 q + 7 of
-// a 32-deep step for one 16-column fragment, the two 32-byte halves of a granule swapped on rows with bit 3 set so the two groups
-// of a 32-lane half - rows 8 apart, same 16 columns - stay conflict-free) passes the same tests and measured 0.5 % SLOWER in the
-// train step on both tile sets (profiles/r04_tr_mfma16_ab.txt): kept for the A/B, not the default.
+// The matrix instruction is v_mfma_f32_32x32x16_bf16.  A v_mfma_f32_16x16x32_bf16 build of the main loop (the shape that bought
+// gemm_bf16.hip 2 % inside the models; same sums bit for bit; lane group q reads reduction rows 8 q .. 8 q + 7 of a 32-deep step for
+// one 16-column fragment, the two 32-byte halves of a granule swapped on rows with bit 3 set so the two groups of a 32-lane half -
+// rows 8 apart, same 16 columns - stay conflict-free) passed the same tests and measured 0.5 - 1.2 % SLOWER in the train step
+// (profiles/r04_tr_mfma16_ab.txt); it lived in this file as -DLDIT_TR_MFMA16 from commit 9cb824f to d318110.
 // Reduction rows past the end (tokens are not a multiple of 64) are fetched from a page of zeros: LDS-DMA has no predication.
 //
 // Main loop (round 4: the pipeline of gemm_bf16.hip; rounds 2-3 ran a simple issue-all / read / multiply / barrier loop that left the
 // matrix pipe idle through every DMA burst, every hand-over and the first fragment reads behind it - the dgrad of fc2 took 115 us
 // where the forward GEMM of the same shape takes 72): two LDS stages, ONE barrier per 64-deep k-tile placed in front of the last
 // 16-deep step, whose MFMAs run while the first fragments of the next tile are read and the DMA of the tile after it is issued
-// into the stage the barrier just freed; on the eight-wave tiles one wave per SIMD issues the pieces (its partner's MFMAs cover
+// into the stage the barrier just freed; inside a step the order reads | MFMAs | wait is pinned by hand (below); on the eight-wave tiles one wave per SIMD issues the pieces (its partner's MFMAs cover
 // the issue stalls).  Same swapped-operand accumulator layout and epilogues as gemm_bf16.hip (fp32 / split-K slabs, bf16, dgrad x
 // saved GELU derivative, column sums).
 #include <cstdlib>
