@@ -382,8 +382,10 @@ int ldit_vit_forward_train(const ldit_cfg *cfg, const void *packed, const void *
 /* Backward through stages stage_hi .. stage_lo (stage l >= 1 = encoder layer l, stage 0 = embeddings); a full backward is
  * (layers, 0).  Splitting it into consecutive descending ranges lets the caller start the gradient all-reduce of finished
  * layers while earlier ones are still being differentiated; the running gradient of the residual stream lives in
- * `workspace` between calls.  dtaps[i] (device fp32 [batch, 1+P, C] or NULL) = gradient of the loss with respect to hidden
- * state cfg->taps[i].  grads: flat fp32 block, OVERWRITTEN (not accumulated) for every parameter of the stages processed.
+ * `workspace` between calls, so the ranges of one backward pass run in descending order on ONE workspace and every call gets the
+ * same dtaps array (the gradient arriving at hidden state s < layers is summed in by the call that finishes stage s + 1, in the same
+ * pass over the rows as that layer's LayerNorm backward).  dtaps[i] (device fp32 [batch, 1+P, C] or NULL) = gradient of the loss with
+ * respect to hidden state cfg->taps[i].  grads: flat fp32 block, OVERWRITTEN (not accumulated) for every parameter of the stages processed.
  * drop_scales: the pointer given to the forward (NULL there = NULL here).  x: the forward's input (patch-embedding wgrad). */
 int ldit_vit_backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, const void *x, int32_t batch, void *const *dtaps,
                       const void *drop_scales, const void *saved, size_t saved_bytes, void *grads, size_t grads_bytes,

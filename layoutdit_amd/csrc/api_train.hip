@@ -286,12 +286,24 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, c
     const int rows_lnr = C <= 1024 ? layernorm_bwd_resid_blocks((int64_t)M) : rows_ln;     // partial rows of the fused LayerNorm + LayerScale backward
     ReduceJobs jobs;
 
-    if (stage_hi == g.L) LDIT_HIP_CHECK(hipMemsetAsync(dh, 0, act * 4, stream));
+    // Upstream gradient arriving at hidden state `st` (dtaps).  For the last hidden state it IS dh's first value (a copy; anything
+    // more is added); for every other state it rides in the LayerNorm backward that completes dh for that state - layer st's
+    // layernorm_before, the last kernel of iteration st + 1, in this call or the previous stage's - so dh makes no extra round trip.
+    // (Stages run L .. 0 in order on one workspace: dh itself already travels from call to call.)
+    auto tap_grads = [&](int st, const float *(&found)[8]) {
+        int n = 0;
+        for (int i = 0; dtaps && i < cfg->n_taps && n < 8; ++i)
+            if (cfg->taps[i] == st && dtaps[i]) found[n++] = static_cast<const float *>(dtaps[i]);
+        return n;
+    };
+    if (stage_hi == g.L) {
+        const float *t[8];
+        const int n = tap_grads(g.L, t);
+        if (n == 0) LDIT_HIP_CHECK(hipMemsetAsync(dh, 0, act * 4, stream));
+        else LDIT_HIP_CHECK(hipMemcpyAsync(dh, t[0], act * 4, hipMemcpyDeviceToDevice, stream));
+        for (int i = 1; i < n; ++i) LDIT_RUN(probe, LDIT_K_OTHER, launch_add_inplace(dh, t[i], act, stream));
+    }
     for (int st = stage_hi; st >= stage_lo; --st) {
-        // upstream gradient arriving at hidden state `st`
-        for (int i = 0; dtaps && i < cfg->n_taps; ++i)
-            if (cfg->taps[i] == st && dtaps[i])
-                LDIT_RUN(probe, LDIT_K_OTHER, launch_add_inplace(dh, static_cast<const float *>(dtaps[i]), act, stream));
         if (st == 0) break;
         const int l = st - 1;
         const PackedLayer &pl = pm.layer[l], &gl = gm.layer[l];
@@ -324,10 +336,16 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, c
         LDIT_RUN(probe, LDIT_K_OTHER, launch_colsum_bf16(dqkv, M, 3 * C, 3 * C, PART(7), stream));
         LDIT_TRY(wgrad(probe, jobs, dqkv, 3 * C, S + sl.y1, C, GR(gl.wqkv), reinterpret_cast<float *>(ws + wm.slab[3]), 3 * C, C, M, zeros, stream));
         LDIT_TRY(dgrad(probe, dqkv, 3 * C, W16 + gl.wqkv / 2, dy, M, C, EPI_F32, nullptr, zeros, stream));
-        LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bwd(dy, reinterpret_cast<const float *>(S + sl.h_in), F32(pl.ln1_w), dh, M, C,
-                                                              cfg->ln_eps, PART(8), PART(9), stream));
+        {
+            // dh becomes the gradient at hidden state st - 1: that state's tap gradient (if any) is summed in the same pass
+            const float *t[8];
+            const int n = tap_grads(st - 1, t);
+            LDIT_RUN(probe, LDIT_K_LAYERNORM, launch_layernorm_bwd(dy, reinterpret_cast<const float *>(S + sl.h_in), F32(pl.ln1_w), dh, M, C,
+                                                                  cfg->ln_eps, PART(8), PART(9), stream, n ? t[0] : nullptr));
+            for (int i = 1; i < n; ++i) LDIT_RUN(probe, LDIT_K_OTHER, launch_add_inplace(dh, t[i], act, stream));
+        }
         // ---- second stage of this layer's reductions: 4 wgrad slab sums (queued above) + 10 vectors, one launch ----------
-        if (jobs.n + 10 > 16) LDIT_RUN(probe, LDIT_K_OTHER, launch_reduce_jobs(jobs, stream));
+        if (jobs.n + 12 > 16) LDIT_RUN(probe, LDIT_K_OTHER, launch_reduce_jobs(jobs, stream));
         jobs.add(PART(0), GR(gl.lam2), C, rows_tile, C);
         jobs.add(PART(1), GR(gl.b2), C, rows_tile, C);
         jobs.add(PART(2), GR(gl.b1), F, F % 256 == 0 ? gemm_bf16_tr_colsum_rows(M, F) : rows_tile, F);
@@ -335,12 +353,13 @@ int backward(const ldit_cfg *cfg, const void *flat_params, const void *packed, c
         jobs.add(PART(4), GR(gl.ln2_b), C, rows_lnr, C);
         jobs.add(PART(5), GR(gl.lam1), C, rows_lnr, C);
         jobs.add(PART(6), GR(gl.bo), C, rows_lnr, C);
-        jobs.add(PART(7), GR(gl.bqkv), 3 * C, rows_tile, 3 * C);
+        // q | k | v bias gradient: BEiT has no key bias (TF:306) - its slot in the fused vector is written as a sum of ZERO partial rows
+        jobs.add(PART(7), GR(gl.bqkv), C, rows_tile, 3 * C);
+        jobs.add(PART(7), GR(gl.bqkv) + C, C, 0, 3 * C);
+        jobs.add(PART(7) + 2 * C, GR(gl.bqkv) + 2 * C, C, rows_tile, 3 * C);
         jobs.add(PART(8), GR(gl.ln1_w), C, rows_ln, C);
         jobs.add(PART(9), GR(gl.ln1_b), C, rows_ln, C);
         LDIT_RUN(probe, LDIT_K_OTHER, launch_reduce_jobs(jobs, stream));
-        // BEiT has no key bias (TF:306): its slot in the fused bias gradient stays exactly zero
-        LDIT_HIP_CHECK(hipMemsetAsync(GR(gl.bqkv) + C, 0, (size_t)C * 4, stream));
     }
     if (stage_lo == 0) {
         // ---- embeddings: h0[b, 0] = cls + pos[0];  h0[b, 1 + i] = patch_i . Wp^T + bp + pos[1 + i]  (TF:81-90, 168-172) ------

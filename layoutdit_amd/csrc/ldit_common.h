@@ -300,7 +300,7 @@ int launch_rows_to_bf16(const float *src, void *dst, int M, int N, int skip_toke
 int layernorm_bwd_blocks(int64_t rows);
 int layernorm_bwd_resid_blocks(int64_t rows);
 int launch_layernorm_bwd(const float *dy, const float *x, const float *g, float *dh, int64_t rows, int C, float eps,
-                         float *dg_part, float *db_part, hipStream_t stream);
+                         float *dg_part, float *db_part, hipStream_t stream, const float *add = nullptr);   // add: one more [rows, C] gradient summed into dh
 int launch_layernorm_bwd_resid(const float *dy, const float *x, const float *g, float *dh, int64_t rows, int C, float eps,
                                float *dg_part, float *db_part, const void *z, const float *lam, const float *rowscale, void *dz,
                                float *dlam_part, float *dzb_part, hipStream_t stream);

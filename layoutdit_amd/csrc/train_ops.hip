@@ -217,6 +217,7 @@ struct ResidFused {
     const float *rowscale;    // [rows] stochastic-depth factors or null
     bf16_t *dz;               // [rows, C] out
     float *dlam_part, *dzb_part;   // [blocks, C] out
+    const float *add;         // [rows, C] or null: one more gradient arriving at this hidden state (a tap's), added to dh in the same pass (RES or not)
 };
 
 template <int VPL, int NWV, bool RES>
@@ -262,6 +263,11 @@ __global__ void __launch_bounds__(64 * NWV) layernorm_bwd_rows(const float *__re
                 v[u] = x4[idx];
                 d[u] = d4[idx];
                 acc[u] = h4[idx];
+                if (rf.add) {
+                    const f32x4 t = reinterpret_cast<const f32x4 *>(rf.add + row * C)[idx];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[u][e] += t[e];
+                }
                 if (RES) {
                     zr[u] = reinterpret_cast<const bf16x4 *>(rf.z + row * C)[idx];
                     gg[u] = gp[idx];
@@ -686,9 +692,11 @@ static int launch_layernorm_bwd_t(const float *dy, const float *x, const float *
 }
 
 int launch_layernorm_bwd(const float *dy, const float *x, const float *g, float *dh, int64_t rows, int C, float eps,
-                         float *dg_part, float *db_part, hipStream_t stream)
+                         float *dg_part, float *db_part, hipStream_t stream, const float *add)
 {
-    return launch_layernorm_bwd_t<false>(dy, x, g, dh, rows, C, eps, dg_part, db_part, ResidFused{}, stream);
+    ResidFused rf{};
+    rf.add = add;
+    return launch_layernorm_bwd_t<false>(dy, x, g, dh, rows, C, eps, dg_part, db_part, rf, stream);
 }
 
 // LayerNorm backward + the LayerScale / residual backward of the branch below it (dz, and the partial sums of dz and of dh z rs per
@@ -697,7 +705,7 @@ int launch_layernorm_bwd_resid(const float *dy, const float *x, const float *g, 
                                float *dg_part, float *db_part, const void *z, const float *lam, const float *rowscale, void *dz,
                                float *dlam_part, float *dzb_part, hipStream_t stream)
 {
-    ResidFused rf;
+    ResidFused rf{};
     rf.z = static_cast<const bf16_t *>(z); rf.lam = lam; rf.rowscale = rowscale; rf.dz = static_cast<bf16_t *>(dz);
     rf.dlam_part = dlam_part; rf.dzb_part = dzb_part;
     return launch_layernorm_bwd_t<true>(dy, x, g, dh, rows, C, eps, dg_part, db_part, rf, stream);
