@@ -62,6 +62,7 @@ DiagSwitches read_switches()
     d.bf16_tile = digit("LDIT_GEMM_BF16_TILE", 2, 7);
     d.bf16_tile_env = getenv("LDIT_GEMM_BF16_TILE") != nullptr;
     d.bf16_tr_tile = digit("LDIT_GEMM_BF16_TR_TILE", 0, 9);
+    d.bf16_tail_launch = is("LDIT_GEMM_BF16_TAIL_LAUNCH", '1');
     d.fp8_tile = digit("LDIT_GEMM_FP8_TILE", 0, 6);
     d.fp8_k16 = is("LDIT_GEMM_FP8_K16", '1');
     d.fp8_noskinny = is("LDIT_GEMM_FP8_NOSKINNY", '1');

@@ -31,6 +31,71 @@ namespace {
 
 // WM x WN waves per workgroup, each owning TM x TN 32x32 tiles.  2 x 4 waves (512 threads, two waves per SIMD) let one
 // wave's MFMAs cover the other's LDS reads, DMA issue and barrier waits.
+// One wave, one 32 x 16 output tile over all of K (the tail kernel's body - see gemm_bf16_tail below for what it promises; it stands
+// in front of the tile kernel because a peeled tail now rides in the main launch as a few extra workgroups, each wave one tile).
+template <int EPI>
+__device__ __forceinline__ void tail_tile(const GemmArgsH &p, int tile, int lane)
+{
+    // A register set holds GPS GROUPS; a group = one 64-deep k-tile of one plane segment = two 32-deep steps (ordinary GEMM: one
+    // segment, so groups are the k-tiles in order).  Split-fp32 operands (GemmExtra::nseg): the groups are walked in the tile kernels'
+    // order (k-tile outermost when seg_inner, else segment outermost), so that a row gets the tile kernels' bits here too - which
+    // lets small batches of those builds run on this latency-oriented kernel.
+    constexpr int GPS = 4;                                // groups per register set (two sets: 16 steps of 32 in flight per wave)
+    const int r16 = lane & 15, q16 = lane >> 4;
+    const int nct = (p.N + 15) / 16;
+    const int n0 = (tile % nct) * 16, m0 = (tile / nct) * 32;
+    const bool two = m0 + 16 < p.M;                       // block-uniform: the second 16-row sub-tile has a valid row
+    const int ra0 = m0 + r16 < p.M ? m0 + r16 : p.M - 1, ra1 = m0 + 16 + r16 < p.M ? m0 + 16 + r16 : p.M - 1;
+    const int rw = n0 + r16 < p.N ? n0 + r16 : p.N - 1;
+    const bf16_t *ap0 = p.A + (size_t)ra0 * p.lda + 8 * q16, *ap1 = p.A + (size_t)ra1 * p.lda + 8 * q16;
+    const bf16_t *wp = p.W + (size_t)rw * p.ldw + 8 * q16;
+    const int nkb = p.K / BKB, nseg = p.x.nseg > 0 ? p.x.nseg : 1, ngroups = nkb * nseg;
+    f32x4 acc[2][1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[0][0][e] = 0.0f; acc[1][0][e] = 0.0f; }
+    struct Set { bf16x8 a0[2 * GPS], a1[2 * GPS], w[2 * GPS]; };
+    Set s0, s1;
+    auto ld = [&](Set &s, int g0) {
+#pragma unroll
+        for (int gi = 0; gi < GPS; ++gi) {
+            int G = g0 + gi < ngroups ? g0 + gi : ngroups - 1;            // clamped: a group past the end is loaded, never multiplied
+            int seg = 0, kb = G;
+            if (p.x.nseg > 1) {
+                if (p.x.seg_inner) { kb = G / nseg; seg = G - kb * nseg; }
+                else { seg = G / nkb; kb = G - seg * nkb; }
+            }
+            const unsigned ka = ((p.x.seg_a >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)kb * BKB;
+            const unsigned kw = ((p.x.seg_w >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)kb * BKB;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                s.a0[2 * gi + st] = *reinterpret_cast<const bf16x8 *>(ap0 + ka + 32 * st);
+                if (two) s.a1[2 * gi + st] = *reinterpret_cast<const bf16x8 *>(ap1 + ka + 32 * st);
+                s.w[2 * gi + st] = *reinterpret_cast<const bf16x8 *>(wp + kw + 32 * st);
+            }
+        }
+    };
+    auto mm = [&](const Set &s, int g0) {
+#pragma unroll
+        for (int gi = 0; gi < GPS; ++gi)
+            if (g0 + gi < ngroups)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s.w[2 * gi + st], s.a0[2 * gi + st], acc[0][0], 0, 0, 0);
+                    if (two) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s.w[2 * gi + st], s.a1[2 * gi + st], acc[1][0], 0, 0, 0);
+                }
+    };
+    ld(s0, 0);
+    for (int g0 = 0; g0 < ngroups; g0 += 2 * GPS) {
+        ld(s1, g0 + GPS);
+        mm(s0, g0);
+        ld(s0, g0 + 2 * GPS);
+        mm(s1, g0 + GPS);
+    }
+    // rows of a skipped second sub-tile are >= M: the row check of the direct store drops them
+    if ((n0 + 16 <= p.N) && ((p.ldy & 3) == 0)) store_h<1, 1, EPI, 1, true, 1>(p, acc, m0, n0, lane);
+    else store_h<1, 1, EPI, 2, true, 1>(p, acc, m0, n0, lane);
+}
+
 template <int WM, int WN, int TM, int TN, int EPI>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(const GemmArgsH p0)
 {
@@ -54,6 +119,25 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
 
     const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
     const int ntiles = nbm * nbn, nblocks = ntiles * p.x.splits;
+    if (p.x.tail_rows > 0 && (int)blockIdx.x >= nblocks) {
+        // The peeled tail of THIS GEMM (launch_gemm_bf16_ex): rows M .. M + tail_rows - 1, one 32 x 16 tile per wave of the workgroups
+        // behind the last tile - the same code, hence the same bits, as the separate gemm_bf16_tail launch it replaces (round 4:
+        // one launch and one kernel boundary less per GEMM of ViT-L 512^2, M = 64 x 256 + 16).
+        GemmArgsH t = p;
+        const size_t r = (size_t)p.M;
+        t.A = p.A + r * (size_t)p.lda;
+        t.Y = static_cast<char *>(p.Y) + r * (size_t)p.ldy * (f32_out<EPI>() ? 4 : 2);
+        if (p.R) t.R = p.R + r * (size_t)p.ldy;
+        if (p.Y2) t.Y2 = p.Y2 + r * (size_t)p.ldy;
+        if (p.x.Ypre) t.x.Ypre = static_cast<char *>(p.x.Ypre) + r * (size_t)p.ldy * 2;
+        if (p.x.rowscale) t.x.rowscale = p.x.rowscale + r;
+        if (p.x.aux) t.x.aux = static_cast<const char *>(p.x.aux) + r * (size_t)p.x.ldaux * 2;
+        t.M = p.x.tail_rows;
+        t.x.tail_rows = 0;
+        // (ONE tile per workgroup, on its first wave: the tail chain is load-issue bound, eight of them on one CU ran 3 x slower)
+        if (wave == 0) tail_tile<EPI>(t, (int)blockIdx.x - nblocks, lane);
+        return;
+    }
     int tile;
     {
         const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = nblocks >> 3, rr = nblocks & 7;
@@ -466,7 +550,10 @@ int launch_h(const GemmArgsH &a, hipStream_t stream)
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     auto kern = gemm_bf16_mfma<WM, WN, TM, TN, EPI>;
     LDIT_DYN_LDS(kern, lds);
-    hipLaunchKernelGGL(kern, dim3(tiles * a.x.splits), dim3(64 * WM * WN), lds, stream, a);
+    // (+ one workgroup per 32 x 16 tile of a peeled tail riding in this launch)
+    const int tail_tiles = a.x.tail_rows > 0 ? ((a.N + 15) / 16) * ((a.x.tail_rows + 31) / 32) : 0;
+    const int tail_blocks = tail_tiles;
+    hipLaunchKernelGGL(kern, dim3(tiles * a.x.splits + tail_blocks), dim3(64 * WM * WN), lds, stream, a);
     LDIT_HIP_CHECK(hipGetLastError());
     return LDIT_OK;
 }
@@ -487,64 +574,7 @@ int launch_h(const GemmArgsH &a, hipStream_t stream)
 template <int EPI>
 __global__ void __launch_bounds__(64) gemm_bf16_tail(const GemmArgsH p)
 {
-    // A register set holds GPS GROUPS; a group = one 64-deep k-tile of one plane segment = two 32-deep steps (ordinary GEMM: one
-    // segment, so groups are the k-tiles in order).  Split-fp32 operands (GemmExtra::nseg): the groups are walked in the tile kernels'
-    // order (k-tile outermost when seg_inner, else segment outermost), so that a row gets the tile kernels' bits here too - which
-    // lets small batches of those builds run on this latency-oriented kernel.
-    constexpr int GPS = 4;                                // groups per register set (two sets: 16 steps of 32 in flight per wave)
-    const int lane = threadIdx.x, r16 = lane & 15, q16 = lane >> 4;
-    const int nct = (p.N + 15) / 16;
-    const int n0 = (blockIdx.x % nct) * 16, m0 = (blockIdx.x / nct) * 32;
-    const bool two = m0 + 16 < p.M;                       // block-uniform: the second 16-row sub-tile has a valid row
-    const int ra0 = m0 + r16 < p.M ? m0 + r16 : p.M - 1, ra1 = m0 + 16 + r16 < p.M ? m0 + 16 + r16 : p.M - 1;
-    const int rw = n0 + r16 < p.N ? n0 + r16 : p.N - 1;
-    const bf16_t *ap0 = p.A + (size_t)ra0 * p.lda + 8 * q16, *ap1 = p.A + (size_t)ra1 * p.lda + 8 * q16;
-    const bf16_t *wp = p.W + (size_t)rw * p.ldw + 8 * q16;
-    const int nkb = p.K / BKB, nseg = p.x.nseg > 0 ? p.x.nseg : 1, ngroups = nkb * nseg;
-    f32x4 acc[2][1];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { acc[0][0][e] = 0.0f; acc[1][0][e] = 0.0f; }
-    struct Set { bf16x8 a0[2 * GPS], a1[2 * GPS], w[2 * GPS]; };
-    Set s0, s1;
-    auto ld = [&](Set &s, int g0) {
-#pragma unroll
-        for (int gi = 0; gi < GPS; ++gi) {
-            int G = g0 + gi < ngroups ? g0 + gi : ngroups - 1;            // clamped: a group past the end is loaded, never multiplied
-            int seg = 0, kb = G;
-            if (p.x.nseg > 1) {
-                if (p.x.seg_inner) { kb = G / nseg; seg = G - kb * nseg; }
-                else { seg = G / nkb; kb = G - seg * nkb; }
-            }
-            const unsigned ka = ((p.x.seg_a >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)kb * BKB;
-            const unsigned kw = ((p.x.seg_w >> (4 * seg)) & 15u) * (unsigned)p.K + (unsigned)kb * BKB;
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                s.a0[2 * gi + st] = *reinterpret_cast<const bf16x8 *>(ap0 + ka + 32 * st);
-                if (two) s.a1[2 * gi + st] = *reinterpret_cast<const bf16x8 *>(ap1 + ka + 32 * st);
-                s.w[2 * gi + st] = *reinterpret_cast<const bf16x8 *>(wp + kw + 32 * st);
-            }
-        }
-    };
-    auto mm = [&](const Set &s, int g0) {
-#pragma unroll
-        for (int gi = 0; gi < GPS; ++gi)
-            if (g0 + gi < ngroups)
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s.w[2 * gi + st], s.a0[2 * gi + st], acc[0][0], 0, 0, 0);
-                    if (two) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s.w[2 * gi + st], s.a1[2 * gi + st], acc[1][0], 0, 0, 0);
-                }
-    };
-    ld(s0, 0);
-    for (int g0 = 0; g0 < ngroups; g0 += 2 * GPS) {
-        ld(s1, g0 + GPS);
-        mm(s0, g0);
-        ld(s0, g0 + 2 * GPS);
-        mm(s1, g0 + GPS);
-    }
-    // rows of a skipped second sub-tile are >= M: the row check of the direct store drops them
-    if ((n0 + 16 <= p.N) && ((p.ldy & 3) == 0)) store_h<1, 1, EPI, 1, true, 1>(p, acc, m0, n0, lane);
-    else store_h<1, 1, EPI, 2, true, 1>(p, acc, m0, n0, lane);
+    tail_tile<EPI>(p, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 template <int EPI>
@@ -672,6 +702,13 @@ int launch_gemm_bf16_ex(const void *A, int lda, const void *W, const float *bias
     // (nor is a split-fp32 product: the tail kernel walks one K range)
     if (rem != 0 && rem <= 64 && M > 256 && x.splits == 1 && epi != EPI_EMBED && x.nseg == 0 && (full + 255) / 256 > (mainp + 255) / 256) {   // peel only when it saves a round
         const int main_rows = M - rem;
+        if (!diag().bf16_tail_launch) {
+            // the tail rides in the main launch (extra workgroups behind the last tile, gemm_bf16_mfma); LDIT_GEMM_BF16_TAIL_LAUNCH=1
+            // keeps the two launches of round 3 for the A/B - the rows get the same bits either way
+            GemmExtra xm = x;
+            xm.tail_rows = rem;
+            return launch_gemm_bf16_one(A, lda, W, bias, Y, ldy, main_rows, N, K, epi, lam, R, Y2, xm, stream);
+        }
         const size_t out_elt = (epi == EPI_SCALE_RESID || epi == EPI_F32) ? 4 : 2;
         int rc = launch_gemm_bf16_one(A, lda, W, bias, Y, ldy, main_rows, N, K, epi, lam, R, Y2, x, stream);
         if (rc != LDIT_OK) return rc;

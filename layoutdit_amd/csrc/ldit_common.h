@@ -54,6 +54,7 @@ struct DiagSwitches {
     int bf16_tile = -1;          // LDIT_GEMM_BF16_TILE 2..5 (-1 = picker; any value also disables the small-M kernel)
     bool bf16_tile_env = false;  //   the variable is present at all
     int bf16_tr_tile = -1;       // LDIT_GEMM_BF16_TR_TILE
+    bool bf16_tail_launch = false;   // LDIT_GEMM_BF16_TAIL_LAUNCH=1: the peeled tail of a bf16 GEMM as its own launch (round 3) instead of riding in the main one
     int fp8_tile = -1;           // LDIT_GEMM_FP8_TILE 0..4
     bool fp8_k16 = false, fp8_noskinny = false;   // LDIT_GEMM_FP8_K16, LDIT_GEMM_FP8_NOSKINNY
     bool direct_epi = false;     // LDIT_GEMM_DIRECT_EPILOGUE=1
@@ -167,6 +168,9 @@ struct GemmExtra {
     // over the tensor used to collect.  colsum[r][n], r = (row tile index * waves along M + wave row): one fp32 partial row per
     // wave row of every tile, `colsum_rows(M, BM, WM)` of them, summed afterwards by launch_reduce_jobs; row stride = N.
     float *colsum = nullptr;
+    // gemm_bf16.hip: rows M .. M + tail_rows - 1 of the same operands (the peeled ragged tail) are computed by extra workgroups of the
+    // SAME launch, one 32 x 16 tile per wave (0 = no tail rides along)
+    int tail_rows = 0;
 };
 
 // x ~= p[0] + p[1] (+ p[2]): the bf16 planes of the split-fp32 build.  Every subtraction is exact in fp32.

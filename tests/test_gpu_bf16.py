@@ -217,6 +217,35 @@ def test_linear_bf16_tail_rows_have_the_bits_of_tile_rows(M, N, K, rows, tile):
         assert torch.equal(big[M - rows:], small), (epi, tile)
 
 
+def test_peeled_tail_rides_in_the_main_launch_with_the_bits_of_its_own_launch():
+    """M = 64 x 256 + 16 rows (ViT-L/16 512 x 512 at bs=16) and N = 1024: the 16 rows past the last full tile row would cost a second
+    round of the machine, so they are peeled - since round 4 as extra workgroups of the SAME launch (one 32 x 16 tile each), before
+    that as a launch of their own (LDIT_GEMM_BF16_TAIL_LAUNCH=1 keeps it).  Both give the rows the bits they get when they are
+    computed alone, for every epilogue, and leave the main rows untouched."""
+    M, N, K, rows = 64 * 256 + 16, 1024, 192, 16
+    x, w, b = _bf16_round(_rand(70, M, K)), _bf16_round(_rand(71, N, K, scale=0.05)), _rand(72, N, scale=0.1)
+    xd, wd, bd = (torch.from_numpy(x).to(DEV).to(torch.bfloat16), torch.from_numpy(w).to(DEV).to(torch.bfloat16),
+                  torch.from_numpy(b).to(DEV))
+    lam, r = torch.from_numpy(np.abs(_rand(73, N)) * 0.3 + 0.05).to(DEV), torch.from_numpy(_rand(74, M, N)).to(DEV)
+    xt = xd[M - rows:].contiguous()
+    try:
+        for epi in (_lib.EPI_BIAS, _lib.EPI_BIAS_GELU, _lib.EPI_SCALE_RESID):
+            kw = dict(lam=lam, residual=r) if epi == _lib.EPI_SCALE_RESID else {}
+            kt = dict(lam=lam, residual=r[M - rows:].contiguous()) if epi == _lib.EPI_SCALE_RESID else {}
+            _lib.set_switch("LDIT_GEMM_BF16_TAIL_LAUNCH", None)
+            riding = ops.linear_bf16(xd, wd, bd, epilogue=epi, **kw)
+            small = ops.linear_bf16(xt, wd, bd, epilogue=epi, **kt)
+            _lib.set_switch("LDIT_GEMM_BF16_TAIL_LAUNCH", "1")
+            apart = ops.linear_bf16(xd, wd, bd, epilogue=epi, **kw)
+            assert torch.equal(riding, apart), epi
+            assert torch.equal(riding[M - rows:], small), epi
+            ref = torch.from_numpy(x[:64]).double() @ torch.from_numpy(w).double().T + torch.from_numpy(b).double()
+            if epi == _lib.EPI_BIAS:
+                assert rel_l2(riding[:64].float().cpu().numpy(), ref.numpy()) < 1e-2
+    finally:
+        _lib.set_switch("LDIT_GEMM_BF16_TAIL_LAUNCH", None)
+
+
 def test_forward_bf16_is_batch_invariant():
     """An image's taps do not depend on the batch it rides in: every dot product has a fixed k-order and the epilogues use
     the same explicit fmas on the slab path (interior tiles) and on the direct path (ragged tiles), so bs=64 (M = 12608,
