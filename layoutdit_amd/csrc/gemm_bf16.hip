@@ -524,8 +524,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
 #endif
 
     const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
+    // the slab path stores 16 bytes per lane: eight bf16 columns unless the output is fp32 (epilogue_rows.h)
+    const bool slab_ok = f32_out<EPI>() || ((p.ldy & 7) == 0 && (EPI != EPI_GELU_BWD || (p.x.ldaux & 7) == 0) &&
+                                            (p.x.nsplit_out == 0 || ((p.ldy / p.x.nsplit_out) & 7) == 0));
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
-    if (cols_in && m0 + BM <= p.M && !p.direct_epi) {
+    if (cols_in && slab_ok && m0 + BM <= p.M && !p.direct_epi) {
         __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
         store_rows_via_lds<TM, TN, EPI, f32_out<EPI>() ? EPI_OUT_F32 : (EPI == EPI_GELU_SPLIT || EPI == EPI_BIAS_SPLIT) ? EPI_OUT_SPLIT : EPI_OUT_BF16, L16>(
             acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, nullptr, p.ldy, mw, nw, lane, 1.0f, 1.0f, p.x);

@@ -377,8 +377,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
     __syncthreads();                                      // every wave is out of the k-loop: the stage memory becomes slab buffers
 
     const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
+    // the slab path stores 16 bytes per lane: eight bf16 columns unless the output is fp32 (epilogue_rows.h)
+    const bool slab_ok = f32_out<EPI>() || ((p.ldy & 7) == 0 && (EPI != EPI_GELU_BWD || (p.x.ldaux & 7) == 0) &&
+                                            (p.x.nsplit_out == 0 || ((p.ldy / p.x.nsplit_out) & 7) == 0));
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
-    if (cols_in && (m0 + BM <= p.M || p.x.colsum)) {
+    if (cols_in && slab_ok && (m0 + BM <= p.M || p.x.colsum)) {
         // (with column sums requested the ragged last row tile takes the slab path too, rows past M skipped)
         float *cs = (!f32_out<EPI>() && p.x.colsum) ? p.x.colsum + (size_t)((m0 / BM) * WM + wm) * (size_t)p.ldy : nullptr;
         store_rows_via_lds<TM, TN, EPI, f32_out<EPI>() ? EPI_OUT_F32 : EPI_OUT_BF16, L16>(
@@ -470,7 +473,7 @@ int launch_gemm_bf16_tr(const void *A, int lda, bool a_reduction_major, const vo
     GemmArgsH a{};
     a.A = static_cast<const bf16_t *>(A); a.W = static_cast<const bf16_t *>(W); a.Y = Y; a.bias = bias;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldy = ldy; a.x = x;
-    if (x.colsum && (a_reduction_major || epi == EPI_F32 || x.splits != 1 || (N % 256) || ldy != N || !aligned16(x.colsum)))
+    if (x.colsum && (a_reduction_major || epi == EPI_F32 || x.splits != 1 || (N % 256) || ldy != N || !aligned16(x.colsum) || (x.aux && (x.ldaux & 7))))
         return fail(LDIT_EINVAL, "gemm_bf16_tr: column sums need the dgrad form with a bf16 output, N a multiple of 256 and ldy == N");
     if (a_reduction_major) {
         if (epi != EPI_F32) return fail(LDIT_EINVAL, "gemm_bf16_tr: wgrad form has the fp32 epilogue only");

@@ -342,7 +342,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_fp8_mfma(con
 
     const bool cols_in = (n0 + BN <= p.N) && ((p.ldy & 3) == 0);
     const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
-    if (cols_in && m0 + BM <= p.M && !p.direct_epi) {
+    // (the slab path stores eight bf16 columns per lane - EPI_BIAS, the q|k|v output -: ldy a multiple of 8 then)
+    if (cols_in && (EPI != EPI_BIAS || (p.ldy & 7) == 0) && m0 + BM <= p.M && !p.direct_epi) {
         __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
         const float ab = p.d_act ? p.d_act[0] : p.ab_scale;
         const float oinv = (EPI == EPI_BIAS_GELU && p.d_out) ? 1.0f / p.d_out[0] : p.out_inv_scale;
