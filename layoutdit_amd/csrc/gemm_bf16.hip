@@ -96,15 +96,12 @@ __device__ __forceinline__ void tail_tile(const GemmArgsH &p, int tile, int lane
     else store_h<1, 1, EPI, 2, true, 1>(p, acc, m0, n0, lane);
 }
 
-// CUT (16x16x32 build only): a wave owns 32 TM - 16 rows - its last 16-row fragment does not exist (no loads, no MFMAs, no stores).
-// TM = 3 with CUT is the 160 x 256 tile: 237 tiles for M = 12 608, N = 768 where 192 rows make 198 and leave 58 CUs idle.
-template <int WM, int WN, int TM, int TN, int EPI, bool CUT = false>
+template <int WM, int WN, int TM, int TN, int EPI>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(const GemmArgsH p0)
 {
     GemmArgsH p = p0;
     constexpr int NWAVES = WM * WN;
-    constexpr int RW = 32 * TM - (CUT ? 16 : 0);         // rows per wave
-    constexpr int BM = RW * WM, BN = 32 * TN * WN, ROWS = BM + BN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, ROWS = BM + BN;
     static_assert(BM % 8 == 0, "a DMA piece is eight rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifndef LDIT_BF16_MFMA32
@@ -112,7 +109,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
 #else
     constexpr bool L16 = false;      // A/B build: v_mfma_f32_32x32x16_bf16, as rounds 1-3 (same bits)
 #endif
-    static_assert(!CUT || L16, "a cut wave tile needs the 16-row fragments of the 16x16x32 build");
 
 #ifdef LDIT_GEMM_STAMPS
     const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
@@ -260,15 +256,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
             for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0f;
     const int r16 = lane & 15, q16 = lane >> 4;
     const int sw = (r16 >> 1) & 7;
-    const int a_row = (wm * RW + r16) * ROWB, b_row = (BM + wn * TN * 32 + r16) * ROWB;
+    const int a_row = (wm * TM * 32 + r16) * ROWB, b_row = (BM + wn * TN * 32 + r16) * ROWB;
     // activation fragments of half `hf` (fragments hf * TM .. hf * TM + TM - 1) of 32-deep step k32
     auto load_a = [&](int stage, int k32, int hf, bf16x8(&xa)[TM]) {
         const char *base = smem + stage * (ROWS * ROWB) + ((k32 * 4 + q16) ^ sw) * 16;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if (CUT && hf == 1 && i == TM - 1) continue;       // the fragment a cut wave tile does not have
-            xa[i] = *reinterpret_cast<const bf16x8 *>(base + a_row + (hf * TM + i) * 16 * ROWB);
-        }
+        for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const bf16x8 *>(base + a_row + (hf * TM + i) * 16 * ROWB);
     };
     auto load_w = [&](int stage, int k32, bf16x8(&wb)[2 * TN]) {
         const char *base = smem + stage * (ROWS * ROWB) + ((k32 * 4 + q16) ^ sw) * 16;
@@ -281,7 +274,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
 #pragma unroll
             for (int j = 0; j < 2 * TN; ++j) {
                 if (hf == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
-                else if (!(CUT && i == TM - 1)) acc[TM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[TM + i][j], 0, 0, 0);
+                else acc[TM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[TM + i][j], 0, 0, 0);
             }
     };
 #else
@@ -326,10 +319,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     unsigned long long st_vm = 0, st_bar = 0, st_loop0 = 0, st_real0 = 0;
 #endif
     // one half step's schedule: `nr` LDS reads and `nd` DMA pieces dealt between its NM MFMAs, one per MFMA
-    // (half steps "a" multiply TM row fragments, "b" TM - 1 of them on a cut wave tile: NMA / NMB MFMAs, TMB fragments read for a "b")
-    constexpr int TMB = TM - (CUT ? 1 : 0), NMA = NM, NMB = 2 * TMB * TN;
-    auto deal = [&](auto nr_c, auto nd_c, auto id_c, auto nm_c) {
-        constexpr int NR = decltype(nr_c)::value, ND = decltype(nd_c)::value, ID = decltype(id_c)::value, NM = decltype(nm_c)::value;
+    auto deal = [&](auto nr_c, auto nd_c, auto id_c) {
+        constexpr int NR = decltype(nr_c)::value, ND = decltype(nd_c)::value, ID = decltype(id_c)::value;
         static_assert(NR + ND <= NM, "more reads and pieces than MFMAs in a half step");
 #pragma unroll
         for (int g = 0; g < NR; ++g) {
@@ -369,19 +360,19 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
         load_a(cur, 0, 1, xaB);
         issue_range(cur ^ 1, ka1, kw1, D3, D3 + D0);
         mfma_half(0, xaA, wbX);
-        deal(std::integral_constant<int, TMB>{}, std::integral_constant<int, (D0 < NMA - TMB ? D0 : NMA - TMB)>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, NMA>{});
+        deal(std::integral_constant<int, TM>{}, std::integral_constant<int, (D0 < NM - TM ? D0 : NM - TM)>{}, std::integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
         // ---- (0, b): reads all fragments of (1, a)
         load_a(cur, 1, 0, xaA);
         load_w(cur, 1, wbY);
         issue_range(cur ^ 1, ka1, kw1, D3 + D0, NP);
         mfma_half(1, xaB, wbX);
-        deal(std::integral_constant<int, TM + 2 * TN>{}, std::integral_constant<int, (D1 < NMB - TM - 2 * TN ? D1 : NMB - TM - 2 * TN)>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, NMB>{});
+        deal(std::integral_constant<int, TM + 2 * TN>{}, std::integral_constant<int, (D1 < NM - TM - 2 * TN ? D1 : NM - TM - 2 * TN)>{}, std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
         // ---- (1, a): reads the activation fragments of (1, b)
         load_a(cur, 1, 1, xaB);
         mfma_half(0, xaA, wbY);
-        deal(std::integral_constant<int, TMB>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, NMA>{});
+        deal(std::integral_constant<int, TM>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
         __builtin_amdgcn_sched_barrier(0);
         // ---- hand-over
 #ifdef LDIT_GEMM_STAMPS
@@ -404,7 +395,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
         issue_range(cur, ka2, kw2, 0, D3);
         ka1 = ka2; kw1 = kw2;
         mfma_half(1, xaB, wbY);
-        deal(std::integral_constant<int, TM + 2 * TN>{}, std::integral_constant<int, (D3 < NMB - TM - 2 * TN ? D3 : NMB - TM - 2 * TN)>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, NMB>{});
+        deal(std::integral_constant<int, TM + 2 * TN>{}, std::integral_constant<int, (D3 < NM - TM - 2 * TN ? D3 : NM - TM - 2 * TN)>{}, std::integral_constant<int, 3>{});
     }
     };
 #else
@@ -536,18 +527,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     // the slab path stores 16 bytes per lane: eight bf16 columns unless the output is fp32 (epilogue_rows.h)
     const bool slab_ok = f32_out<EPI>() || ((p.ldy & 7) == 0 && (EPI != EPI_GELU_BWD || (p.x.ldaux & 7) == 0) &&
                                             (p.x.nsplit_out == 0 || ((p.ldy / p.x.nsplit_out) & 7) == 0));
-    const int mw = m0 + wm * RW, nw = n0 + wn * TN * 32;
+    const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
     if (cols_in && slab_ok && m0 + BM <= p.M && !p.direct_epi) {
         __syncthreads();     // every wave is out of the k-loop (and its DMA drained): the stage memory becomes slab buffers
-        // (a cut wave tile: its last 16 accumulator rows are zeros that belong to nobody - the row limit keeps them out of memory)
         store_rows_via_lds<TM, TN, EPI, f32_out<EPI>() ? EPI_OUT_F32 : (EPI == EPI_GELU_SPLIT || EPI == EPI_BIAS_SPLIT) ? EPI_OUT_SPLIT : EPI_OUT_BF16, L16>(
-            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, nullptr, p.ldy, mw, nw, lane, 1.0f, 1.0f, p.x,
-            CUT ? mw + RW : 0x7fffffff);
-    } else if constexpr (CUT) {
-        GemmArgsH pc = p;                                  // direct stores: rows past the wave's own range (and past M) are skipped
-        pc.M = p.M < mw + RW ? p.M : mw + RW;
-        if (cols_in) store_h<TM, TN, EPI, 1, L16>(pc, acc, mw, nw, lane);
-        else store_h<TM, TN, EPI, 2, L16>(pc, acc, mw, nw, lane);
+            acc, smem + wave * EPI_WAVE_BYTES, p.Y, p.Y2, p.R, p.bias, p.lam, nullptr, p.ldy, mw, nw, lane, 1.0f, 1.0f, p.x);
     } else if (cols_in && m0 + BM <= p.M) store_h<TM, TN, EPI, 0, L16>(p, acc, mw, nw, lane);
     else if (cols_in) store_h<TM, TN, EPI, 1, L16>(p, acc, mw, nw, lane);
     else store_h<TM, TN, EPI, 2, L16>(p, acc, mw, nw, lane);
@@ -561,13 +545,13 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
 #endif
 }
 
-template <int WM, int WN, int TM, int TN, int EPI, bool CUT = false>
+template <int WM, int WN, int TM, int TN, int EPI>
 int launch_h(const GemmArgsH &a, hipStream_t stream)
 {
-    constexpr int BM = (32 * TM - (CUT ? 16 : 0)) * WM, BN = 32 * TN * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int lds = 2 * (BM + BN) * ROWB;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    auto kern = gemm_bf16_mfma<WM, WN, TM, TN, EPI, CUT>;
+    auto kern = gemm_bf16_mfma<WM, WN, TM, TN, EPI>;
     LDIT_DYN_LDS(kern, lds);
     // (+ one workgroup per 32 x 16 tile of a peeled tail riding in this launch)
     const int tail_tiles = a.x.tail_rows > 0 ? ((a.N + 15) / 16) * ((a.x.tail_rows + 31) / 32) : 0;
@@ -640,22 +624,12 @@ int launch_h_tiled(const GemmArgsH &a, hipStream_t stream)
     // per output element (bit-identical results), priced as rounds x tile height.
     double best = c256 <= c128 ? c256 : c128;
     const double per256 = a256[EPI] + 19.5e-3 * Ks;
-    // (round 4: 160 rows - a 192-row tile whose waves drop their last 16-row fragment, 16x16x32 build only)
-#ifndef LDIT_BF16_MFMA32
-    for (int bm : {192, 320, 160}) {
-#else
     for (int bm : {192, 320}) {
-#endif
         const long t = sp * ((a.M + bm - 1) / bm) * ((a.N + 255) / 256);
-        const double c = (double)((t + 255) / 256) * per256 * (bm / 256.0) * (bm == 160 ? 1.06 : 1.03);      // handicap: prefer the fitted tiles on ties (the cut tile multiplies 5/6 of a 192-row tile's fragments with all of its hand-overs)
-        if (c < best) { best = c; pick = bm == 192 ? 4 : bm == 320 ? 5 : 6; }
+        const double c = (double)((t + 255) / 256) * per256 * (bm / 256.0) * 1.03;      // 3 % handicap: prefer the fitted tiles on ties
+        if (c < best) { best = c; pick = bm == 192 ? 4 : 5; }
     }
-    if (const int force = diag().bf16_tile; force >= 2 && force <= 6) pick = force;
-#ifdef LDIT_BF16_MFMA32
-    if (pick == 6) pick = 4;
-#else
-    if (pick == 6) return launch_h<2, 4, 3, 2, EPI, true>(a, stream);      // 160 x 256
-#endif
+    if (const int force = diag().bf16_tile; force >= 2 && force <= 5) pick = force;
     switch (pick) {
         case 3: return launch_h<2, 4, 4, 2, EPI>(a, stream);     // 256 x 256, 8 waves (2 per SIMD)
         case 4: return launch_h<2, 4, 3, 2, EPI>(a, stream);     // 192 x 256

@@ -40,7 +40,7 @@ def test_cast_matches_torch_round_to_nearest_even():
     assert torch.equal(got, torch.from_numpy(x).to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("tile", ["auto", "1", "2", "3", "4", "5", "6"])
+@pytest.mark.parametrize("tile", ["auto", "1", "2", "3", "4", "5"])
 @pytest.mark.parametrize("M,N,K", [(37, 50, 64), (394, 576, 192), (1025, 1024, 1024), (513, 3072, 768), (300, 768, 4096)])
 def test_linear_bf16_bias(M, N, K, tile):
     if tile != "auto":
@@ -53,7 +53,7 @@ def test_linear_bf16_bias(M, N, K, tile):
     assert max_rel(y, ref) < 1.6e-2        # <= one bf16 ulp (2^-8) of max(|ref|, 1), plus accumulation noise
 
 
-@pytest.mark.parametrize("tile", ["1", "2", "3", "4", "5", "6"])
+@pytest.mark.parametrize("tile", ["1", "2", "3", "4", "5"])
 def test_linear_bf16_gelu_and_residual(tile):
     _lib.set_switch("LDIT_GEMM_BF16_TILE", tile)
     M, N, K = 394, 320, 128
@@ -196,7 +196,7 @@ def test_linear_bf16_tail(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,rows", [(1040, 1024, 1024, 16), (600, 320, 4096, 64), (528, 200, 192, 37)])
-@pytest.mark.parametrize("tile", ["auto", "2", "3", "4", "5", "6"])
+@pytest.mark.parametrize("tile", ["auto", "2", "3", "4", "5"])
 def test_linear_bf16_tail_rows_have_the_bits_of_tile_rows(M, N, K, rows, tile):
     """Batch invariance at the kernel level: the last `rows` rows computed ALONE (tail kernel) equal, bit for bit, the same
     rows inside the big problem - whichever tile height serves them there (128 / 256 / 192 / 320 rows, or the peeled tail) and

@@ -64,7 +64,7 @@ def test_fuzz_linear_f32(tile):
         assert np.isfinite(y).all()
 
 
-@pytest.mark.parametrize("tile", ["auto", "1", "2", "3", "4", "5", "6"])
+@pytest.mark.parametrize("tile", ["auto", "1", "2", "3", "4", "5"])
 def test_fuzz_linear_bf16(tile):
     if tile != "auto":
         _lib.set_switch("LDIT_GEMM_BF16_TILE", tile)

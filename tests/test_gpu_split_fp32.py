@@ -88,7 +88,7 @@ def test_linear_planes_vs_float64(planes, M, N, K):
     assert gp.shape == (M, planes * N)
     assert rel_l2(_planes_sum(gp, planes).cpu().numpy(), gref) < (2e-5 if planes == 2 else 2e-6)
     # one accumulation chain per output element whatever tile it falls in: every forced tiling gives the same bits
-    for tile in ("2", "3", "4", "5", "6"):
+    for tile in ("2", "3", "4", "5"):
         _lib.set_switch("LDIT_GEMM_BF16_TILE", tile)
         assert torch.equal(ops.linear_planes(xp, wp, planes, _dev(bias)), torch.from_numpy(y).to(DEV)), tile
     _lib.set_switch("LDIT_GEMM_BF16_TILE", None)
