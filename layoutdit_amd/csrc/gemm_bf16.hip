@@ -344,7 +344,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_mfma(co
     asm volatile("s_nop 4" ::: "memory");
     issue_range(0, ka0, kw0, 0, NP);
     issue_range(1, ka1, kw1, 0, D3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile 0 has landed (vmcnt counts down in issue order); the D3 pieces of tile 1 stay in flight under the first k-tile - the
+    // hand-over in front of its last half step waits for them as for every later tile
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D3) : "memory");
     __syncthreads();
 #ifdef LDIT_GEMM_STAMPS
     st_loop0 = __builtin_amdgcn_s_memtime();

@@ -269,7 +269,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN) / 4) gemm_bf16_tr(cons
         issue(0, k_of(0));
         issue(1, k_of(1));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // explicit: the first tiles have landed before anybody reads them
+    // explicit: the first tile has landed before anybody reads it (vmcnt counts down in issue order: this wave's NLW pieces of the
+    // second tile stay in flight under the first k-tile; the hand-over in front of its last step waits for them)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLW) : "memory");
     __syncthreads();
     constexpr std::integral_constant<int, 0> S0{};
     constexpr std::integral_constant<int, 1> S1{};
