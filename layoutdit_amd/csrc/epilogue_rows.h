@@ -70,6 +70,38 @@ __device__ __forceinline__ void store_rows_via_lds(const ACC &acc, char *buf, vo
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            // The slab's global operands (residual rows, stochastic-depth factors, GELU-derivative rows) are fetched HERE, all passes at
+            // once and without a branch in between, before the accumulators even enter LDS.  Fetched inside the pass loop (rounds 1 - 4a:
+            // load, s_waitcnt vmcnt(0), fma, store, per pass) every pass also sat out the ACKNOWLEDGEMENT of the previous pass's
+            // stores - vmcnt counts stores too and retires in order - eight times per slab.  Rows past `mrows` read row mrows - 1.
+            f32x4 resq[(EPI == EPI_SCALE_RESID && OUT == EPI_OUT_F32) ? NPASS : 1];
+            float rsq[(EPI == EPI_SCALE_RESID && OUT == EPI_OUT_F32) ? NPASS : 1];
+            epi_bf16x8 auxq[(EPI == EPI_GELU_BWD && NQ == 2) ? NPASS : 1];
+            if constexpr (EPI == EPI_SCALE_RESID && OUT == EPI_OUT_F32) {
+#pragma unroll
+                for (int r = 0; r < NPASS; ++r) {
+                    int rg = mw + 32 * i + RPP * r + rrow;
+                    rg = rg < mrows ? rg : mrows - 1;
+                    resq[r] = *reinterpret_cast<const f32x4 *>(R + ((unsigned)rg * (unsigned)ldy + n));
+                    rsq[r] = 1.0f;
+                }
+                if (x.rowscale) {
+#pragma unroll
+                    for (int r = 0; r < NPASS; ++r) {
+                        int rg = mw + 32 * i + RPP * r + rrow;
+                        rg = rg < mrows ? rg : mrows - 1;
+                        rsq[r] = x.rowscale[rg];
+                    }
+                }
+            }
+            if constexpr (EPI == EPI_GELU_BWD && NQ == 2) {
+#pragma unroll
+                for (int r = 0; r < NPASS; ++r) {
+                    int rg = mw + 32 * i + RPP * r + rrow;
+                    rg = rg < mrows ? rg : mrows - 1;
+                    auxq[r] = *reinterpret_cast<const epi_bf16x8 *>(static_cast<const __bf16 *>(x.aux) + ((unsigned)rg * (unsigned)x.ldaux + n));
+                }
+            }
             if constexpr (L16) {
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii)
@@ -88,6 +120,17 @@ __device__ __forceinline__ void store_rows_via_lds(const ACC &acc, char *buf, vo
                                      acc[i][2 * jp + jj][4 * g + 3]};
                     *reinterpret_cast<f32x4 *>(buf + c32 * EPI_ROW_BYTES + (32 * jj + 8 * g + 4 * h) * 4) = v;
                 }
+            }
+            // ONE wait for the slab's fetches, here - the empty asm statements take the fetched registers as operands, so hipcc waits for
+            // all of them now (under the slab's LDS traffic) and knows of no pending load inside the pass loop: a vmcnt(N) there, however
+            // generous, would also wait until all but N of the STORES issued so far are acknowledged
+            if constexpr (EPI == EPI_SCALE_RESID && OUT == EPI_OUT_F32) {
+#pragma unroll
+                for (int r = 0; r < NPASS; ++r) asm volatile("" : "+v"(resq[r]), "+v"(rsq[r]));
+            }
+            if constexpr (EPI == EPI_GELU_BWD && NQ == 2) {
+#pragma unroll
+                for (int r = 0; r < NPASS; ++r) asm volatile("" : "+v"(auxq[r]));
             }
 #pragma unroll
             for (int r = 0; r < NPASS; ++r) {
@@ -154,7 +197,8 @@ __device__ __forceinline__ void store_rows_via_lds(const ACC &acc, char *buf, vo
                 if (EPI == EPI_GELU_BWD) {
                     const __bf16 *ap = static_cast<const __bf16 *>(x.aux) + ((unsigned)(mw + 32 * i + row) * (unsigned)x.ldaux + n);
                     if constexpr (NQ == 2) {
-                        const epi_bf16x8 a = *reinterpret_cast<const epi_bf16x8 *>(ap);
+                        (void)ap;
+                        const epi_bf16x8 a = auxq[r];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[0][e] *= (float)a[e]; v[NQ - 1][e] *= (float)a[4 + e]; }
                     } else {
@@ -165,9 +209,9 @@ __device__ __forceinline__ void store_rows_via_lds(const ACC &acc, char *buf, vo
                 }
                 if constexpr (OUT == EPI_OUT_F32) {
                     if (EPI == EPI_SCALE_RESID) {
-                        const f32x4 res = *reinterpret_cast<const f32x4 *>(R + o);
+                        const f32x4 res = resq[r];
                         if (x.rowscale) {
-                            const float rs = x.rowscale[mw + 32 * i + row];
+                            const float rs = rsq[r];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[0][e] = __builtin_fmaf(lamq[0][e] * rs, v[0][e], res[e]);
                         } else {
