@@ -141,6 +141,47 @@ __device__ __forceinline__ void store_panel(const GemmArgs &p, const f32x16 (&ac
 #pragma unroll
         for (int g = 0; g < 4; ++g) dst[g] = load4<VEC>(p, p.R, m0 + 32 * t + c32, nw + 8 * g + 4 * h, true);
     };
+    if constexpr (EPI == EPI_SCALE_RESID && VEC == 1 && T32 > 0) {
+        // Interior tile (round 4): EVERY residual quad of the wave tile is fetched before the first store, waited for once, and the
+        // stores then go out back to back.  The tile-ahead pipeline below left an s_waitcnt vmcnt(0) in front of every 32-row tile's
+        // stores (nine per wave tile) - and vmcnt counts stores: each of them sat out the acknowledgement of the previous tile's
+        // stores (profiles/r04_epilogue_prefetch_ab.txt, the same finding in the bf16 slab epilogue).  R may alias Y (in-place
+        // residual): every element is read before it is written, by the same lane.  144 + 8 registers beside the accumulators: a
+        // workgroup is four waves, one per SIMD - the register file has them.
+        f32x4 ra[T32][4], rh[2], bh[2], lh[2];
+#pragma unroll
+        for (int t = 0; t < T32; ++t) fetch(t, ra[t]);
+        if (HALF) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                rh[it] = load4<VEC>(p, p.R, m0 + 32 * T32 + c16, nw + 16 * it + 4 * q, true);
+                bh[it] = vec4<VEC>(p.bias, nw + 16 * it + 4 * q, p.N);      // (the remainder's bias / lambda quads too: a load behind the
+                lh[it] = vec4<VEC>(p.lam, nw + 16 * it + 4 * q, p.N);       //  stores would wait for every one of them)
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T32; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(ra[t][g]));      // hipcc waits here, once, and knows of no pending load below
+        if (HALF) asm volatile("" : "+v"(rh[0]), "+v"(rh[1]), "+v"(bh[0]), "+v"(bh[1]), "+v"(lh[0]), "+v"(lh[1]));
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < T32; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a = {acc32[t][4 * g + 0], acc32[t][4 * g + 1], acc32[t][4 * g + 2], acc32[t][4 * g + 3]};
+                emit4<EPI, VEC, DUAL>(p, m0 + 32 * t + c32, nw + 8 * g + 4 * h, a, bias32[g], lam32[g], ra[t][g]);
+            }
+        if (HALF) {
+            const int m = m0 + 32 * T32 + c16;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int n = nw + 16 * it + 4 * q;
+                emit4<EPI, VEC, DUAL>(p, m, n, acc16[it], bh[it], lh[it], rh[it]);
+            }
+        }
+        return;
+    }
     if (EPI == EPI_SCALE_RESID && T32 > 0) fetch(0, res[0]);
 #pragma unroll
     for (int t = 0; t < T32; ++t) {
